@@ -1,0 +1,183 @@
+/*
+ * rtmi.h -- C-ABI of the MI355X-native path-tracing core (librtmi.so).
+ *
+ * Drop-in boundary for ONE hot path of adihodos/raytracing.cpp: the per-pixel path tracer
+ *   RayTracingCore::raytrace_pixel -> get_ray / compute_color -> HittableObject_Collection::intersects
+ *   -> HittableObject_Sphere::intersects -> Material::scatter
+ * (reference src/ray.tracer.core.cc:218-265, src/ray.tracer.object.defs.cc:37-81,
+ *  src/ray.tracer.material.defs.cc:31-109).
+ *
+ * The reference has no FFI; its seam is the C++ call `RGBAColor RayTracingCore::raytrace_pixel(x, y, rng)`
+ * (src/ray.tracer.core.hpp:41) made per pixel of an 8x8 tile by
+ * RayTracingWorker::process_tracing_work_package (src/main.cc:507-519), and the construction seam
+ * `RayTracingCore::default_setup()` (src/ray.tracer.core.hpp:36, called at src/main.cc:604).  A per-pixel
+ * GPU call is meaningless, so the boundary sits one level up, at row-block granularity, with the reference's
+ * own data model: the 14 POD fields of RayTracingCore, the 24-byte HittableObject and the 20-byte Material
+ * records, RGBAColor's 0xAABBGGRR packing.  Plain pointers and sizes only; never throws, never aborts.
+ *
+ * All functions return RTMI_OK (0) or a negative rtmi_status; rtmi_last_error() gives the thread-local text.
+ * The library needs a HIP device (gfx950); there is no CPU fallback.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtmi_status {
+    RTMI_OK = 0,
+    RTMI_ERR_BAD_ARG = -1,   /* null pointer, out-of-range rows, bad material handle, unknown kind */
+    RTMI_ERR_HIP = -2,       /* a HIP runtime call failed (no device, launch failure, ...) */
+    RTMI_ERR_OOM = -3,       /* host or device allocation failed */
+    RTMI_ERR_UNSUPPORTED = -4 /* scene does not fit the selected kernel (e.g. LDS budget) */
+} rtmi_status;
+
+/* CameraParameters, reference src/camera.parameters.hpp:6-17 (same fields, order and types). */
+typedef struct rtmi_camera_params {
+    float aspect_ratio;
+    uint32_t image_width;
+    uint16_t samples_per_pixel;
+    uint16_t max_depth;
+    float vertical_fov;
+    float defocus_angle;
+    float focus_distance;
+    float lookfrom[3];
+    float lookat[3];
+    float world_up[3];
+} rtmi_camera_params;
+
+/* The 14 POD fields of RayTracingCore, reference src/ray.tracer.core.hpp:19-32 (same order and types). */
+typedef struct rtmi_camera {
+    uint32_t img_width;          /* rts_img_width */
+    uint32_t img_height;         /* rts_img_height */
+    float defocus_angle;         /* rts_defocus_angle */
+    float viewport_height;       /* rts_viewport_height (stored, unused by the path) */
+    float viewport_width;        /* rts_viewport_width  (stored, unused by the path) */
+    uint16_t samples_per_pixel;  /* rts_samples_per_pixel */
+    uint16_t maxdepth;           /* rts_maxdepth */
+    float pixels_sample_scale;   /* rts_pixels_sample_scale */
+    float pixel_delta_u[3];      /* rts_pixel_delta_u */
+    float pixel_delta_v[3];      /* rts_pixel_delta_v */
+    float pixel00[3];            /* rts_pixel00 */
+    float cam_center[3];         /* rts_cam_center */
+    float defocus_disk_u[3];     /* rts_defocus_disk_u */
+    float defocus_disk_v[3];     /* rts_defocus_disk_v */
+} rtmi_camera;
+
+/* HittableObject {ObjKind; union {HittableObject_Sphere}}, reference src/ray.tracer.object.defs.hpp:30-57: 24 B. */
+typedef struct rtmi_object {
+    uint32_t kind;     /* HittableObjectKind: 0 = Sphere (hpp:25-28) */
+    float center[3];   /* HittableObject_Sphere::Center */
+    float radius;      /* HittableObject_Sphere::Radius */
+    uint32_t material; /* MaterialHandleType (src/ray.tracer.material.handle.hpp:6): index into materials */
+} rtmi_object;
+
+/* Material {MatKind; union {Lambertian{Albedo}; Metallic{Albedo,Fuzziness}; Dielectric{RefractionIndex}}},
+ * reference src/ray.tracer.material.defs.hpp:20-55: 20 B. */
+typedef struct rtmi_material {
+    uint32_t kind; /* MaterialKind: 0 Lambertian, 1 Metallic, 2 Dielectric (hpp:20-25) */
+    float p[4];    /* Lambertian: p[0..2] albedo; Metallic: p[0..2] albedo, p[3] fuzziness; Dielectric: p[0] index */
+} rtmi_material;
+
+/* WorldDefinition minus camera and objects, reference src/ray.tracer.core.cc:67-95. */
+typedef struct rtmi_world_def {
+    int32_t a_min, a_max, b_min, b_max;
+    float center_offset[3];
+    float center_dist_treshold;
+    float diffuse_material_treshold;
+    float metal_material_treshold;
+} rtmi_world_def;
+
+typedef enum rtmi_accel {
+    RTMI_ACCEL_AUTO = 0,  /* BVH when the scene has more than a handful of objects */
+    RTMI_ACCEL_BRUTE = 1, /* the reference's linear closest-hit scan (object.defs.cc:68-81), spheres in LDS */
+    RTMI_ACCEL_BVH = 2    /* exact-equivalent BVH walk (same closest hit, same tie rule), nodes in LDS */
+} rtmi_accel;
+
+typedef struct rtmi_scene_options {
+    uint32_t struct_size;  /* = sizeof(rtmi_scene_options) */
+    uint32_t accel;        /* rtmi_accel */
+    uint32_t leaf_size;    /* BVH: max spheres per leaf (0 = default) */
+    int32_t device;        /* HIP device ordinal, -1 = current device */
+    uint32_t collect_stats;/* nonzero: kernels also count segments / node tests / sphere tests */
+    uint32_t reserved[3];
+} rtmi_scene_options;
+
+typedef struct rtmi_stats {
+    uint64_t samples, segments, sphere_tests, node_tests;
+} rtmi_stats;
+
+/* flat BVH node as exported by rtmi_scene_get_bvh (for the tests' instrumented CPU walk): 64 B */
+typedef struct rtmi_bvh_node {
+    float ctr[2][3];
+    float half[2][3];
+    uint32_t child[2]; /* bit31 set: leaf {bits 0..23 first slot, bits 24..30 count}; else node index */
+    float reserved[2];
+} rtmi_bvh_node;
+
+typedef struct rtmi_scene rtmi_scene; /* opaque: owns the device copies of camera, objects, materials, BVH */
+
+/* ---- host-side setup (replaces reference src/ray.tracer.core.cc:158-216) -------------------------- */
+
+/* Camera derivation of RayTracingCore::default_setup (core.cc:174-195 + make_camera_frame :158-169). */
+int rtmi_camera_setup(const rtmi_camera_params* params, rtmi_camera* out);
+
+/* Scene generator make_world_spheres (core.cc:99-149) with the RNG seeded from `mt_seed` instead of
+ * std::random_device (random.number.gen.hpp:45-46).  Writes the `n_fixed` listed objects first, then the
+ * a/b grid; returns the object count (== material count) through n_out; capacity is in records. */
+int rtmi_make_world_spheres(const rtmi_world_def* def, const rtmi_object* fixed_objects,
+                            const rtmi_material* fixed_materials, uint32_t n_fixed, uint32_t mt_seed,
+                            rtmi_object* objects_out, rtmi_material* materials_out, uint32_t capacity,
+                            uint32_t* n_out);
+
+/* ---- scene life cycle (replaces the ownership of shared_ptr<RayTracingCore>, main.cc:433,604,669-672) ---- */
+
+/* Uploads camera + world + materials (the reference's rts_world / rts_materials, core.hpp:33-34) and builds
+ * the acceleration structure.  `options` may be NULL. */
+int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
+                      const rtmi_material* materials, uint32_t n_materials, const rtmi_scene_options* options,
+                      rtmi_scene** out);
+void rtmi_scene_destroy(rtmi_scene* scene);
+
+/* ---- the hot path (replaces RayTracingCore::raytrace_pixel per pixel of a tile, core.cc:259-265) -------- */
+
+/* Renders image rows [y0, y1): for every pixel, samples_per_pixel paths of at most maxdepth segments, summed
+ * sequentially in fp32 and scaled by pixels_sample_scale (core.cc:260-264).
+ *   rgb_linear_out  nullable, (y1-y0)*W*3 floats: the value handed to RGBAColor{...} (core.cc:264)
+ *   rgba8_out       nullable, (y1-y0)*W uint32 0xAABBGGRR: RGBAColor(vec3) (color.hpp:30-36)
+ * Random stream: counter-based, keyed by (seed, pixel = y*W + x, sample), independent of tiling, row ranges
+ * and GPU count.  Host pointers; blocking; safe to call concurrently on one scene from several threads. */
+int rtmi_render_rows(rtmi_scene* scene, uint32_t y0, uint32_t y1, uint64_t seed, float* rgb_linear_out,
+                     uint32_t* rgba8_out);
+
+/* Same, row-block sharded and device-resident (multi-GPU path): renders `n_blocks` blocks of `block_rows` rows,
+ * block k covering rows [y_first + k*block_stride*block_rows, +block_rows) clipped to the image, into a dense
+ * slice of n_blocks*block_rows rows.  Outputs are DEVICE pointers (either may be NULL); the launch is
+ * asynchronous on `hip_stream` (a hipStream_t, NULL = default stream). */
+int rtmi_render_row_blocks_device(rtmi_scene* scene, uint32_t y_first, uint32_t block_rows, uint32_t block_stride,
+                                  uint32_t n_blocks, uint64_t seed, void* d_rgb_linear_out, void* d_rgba8_out,
+                                  void* hip_stream);
+
+/* ---- introspection ------------------------------------------------------------------------------------ */
+const char* rtmi_last_error(void);
+const char* rtmi_version(void);
+/* accumulated since scene creation when options.collect_stats != 0 */
+int rtmi_scene_get_stats(rtmi_scene* scene, rtmi_stats* out, int reset);
+/* which kernel rtmi_render_* will launch for this scene: RTMI_ACCEL_BRUTE or RTMI_ACCEL_BVH */
+int rtmi_scene_get_accel(const rtmi_scene* scene, uint32_t* accel_out);
+/* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), 0}. */
+int rtmi_scene_get_bvh(const rtmi_scene* scene, rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out,
+                       uint32_t* n_slots, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,
+                       float* pad_floor);
+/* duration in milliseconds of the most recent kernel launch of this scene, from HIP events recorded on the launch
+ * stream (blocks until that launch has finished); used by bench.py for the roofline line */
+int rtmi_scene_last_kernel_ms(rtmi_scene* scene, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */
