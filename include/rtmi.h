@@ -173,6 +173,11 @@ int rtmi_scene_get_accel(const rtmi_scene* scene, uint32_t* accel_out);
 int rtmi_scene_get_bvh(const rtmi_scene* scene, rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out,
                        uint32_t* n_slots, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,
                        float* pad_floor);
+/* Host-only BVH build (no device needed): the structure rtmi_scene_create would build for these objects.
+ * nodes_out / slots_out need room for n_objects records, pad_classes_out for 32 floats; any output may be NULL. */
+int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, rtmi_bvh_node* nodes_out,
+                   uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref, uint32_t* depth,
+                   float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor);
 /* duration in milliseconds of the most recent kernel launch of this scene, from HIP events recorded on the launch
  * stream (blocks until that launch has finished); used by bench.py for the roofline line */
 int rtmi_scene_last_kernel_ms(rtmi_scene* scene, float* ms_out);

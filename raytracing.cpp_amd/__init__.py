@@ -1,0 +1,321 @@
+"""raytracing.cpp_amd -- MI355X-native path-tracing core (librtmi.so) and its Python plumbing.
+
+The product is the C-ABI shared library built from csrc/ (hand-written HIP for gfx950, see include/rtmi.h)
+plus the C++ host mirror in host/.  This module is the thin ctypes layer that tests, bench.py and
+__graft_entry__.py use to drive that library from Python (device buffers and torch.distributed are plumbing,
+not the product).  It never imports anything from oracle/ and has no CPU fallback: without the HIP library or
+without a GPU every compute call fails loudly.
+
+The directory name contains a dot, so it is loaded through `rtmi_loader.load()` (repo root) rather than a
+plain `import`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "librtmi.so")
+CSRC = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_host.cpp", "rtmi_device.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "rtmi_internal.h"), os.path.join(_ROOT, "include", "rtmi.h")]
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # parity: no FMA contraction, IEEE sqrt/div, denormals kept -- the reference path is plain x86-64 fp32
+    "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-gpu-flush-denormals-to-zero", "-Wno-unused-value",
+]
+
+RTMI_OK = 0
+RTMI_ERR_BAD_ARG, RTMI_ERR_HIP, RTMI_ERR_OOM, RTMI_ERR_UNSUPPORTED = -1, -2, -3, -4
+ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/ for gfx950 with hipcc into librtmi.so (in-tree, so it travels to the GPU box)."""
+    srcs = CSRC + HEADERS
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(_ROOT, "include"), "-o", LIB_PATH] + CSRC
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+class CameraParams(C.Structure):  # rtmi_camera_params == reference src/camera.parameters.hpp:6-17
+    _fields_ = [("aspect_ratio", C.c_float), ("image_width", C.c_uint32), ("samples_per_pixel", C.c_uint16),
+                ("max_depth", C.c_uint16), ("vertical_fov", C.c_float), ("defocus_angle", C.c_float),
+                ("focus_distance", C.c_float), ("lookfrom", C.c_float * 3), ("lookat", C.c_float * 3),
+                ("world_up", C.c_float * 3)]
+
+
+class Camera(C.Structure):  # rtmi_camera == the 14 PODs of RayTracingCore, reference src/ray.tracer.core.hpp:19-32
+    _fields_ = [("img_width", C.c_uint32), ("img_height", C.c_uint32), ("defocus_angle", C.c_float),
+                ("viewport_height", C.c_float), ("viewport_width", C.c_float), ("samples_per_pixel", C.c_uint16),
+                ("maxdepth", C.c_uint16), ("pixels_sample_scale", C.c_float), ("pixel_delta_u", C.c_float * 3),
+                ("pixel_delta_v", C.c_float * 3), ("pixel00", C.c_float * 3), ("cam_center", C.c_float * 3),
+                ("defocus_disk_u", C.c_float * 3), ("defocus_disk_v", C.c_float * 3)]
+
+
+class WorldDef(C.Structure):  # rtmi_world_def == reference src/ray.tracer.core.cc:67-95 minus camera/objects
+    _fields_ = [("a_min", C.c_int32), ("a_max", C.c_int32), ("b_min", C.c_int32), ("b_max", C.c_int32),
+                ("center_offset", C.c_float * 3), ("center_dist_treshold", C.c_float),
+                ("diffuse_material_treshold", C.c_float), ("metal_material_treshold", C.c_float)]
+
+
+class SceneOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("accel", C.c_uint32), ("leaf_size", C.c_uint32), ("device", C.c_int32),
+                ("collect_stats", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("node_tests", C.c_uint64)]
+
+
+OBJECT_DTYPE = np.dtype([("kind", "<u4"), ("center", "<f4", 3), ("radius", "<f4"), ("material", "<u4")])
+MATERIAL_DTYPE = np.dtype([("kind", "<u4"), ("p", "<f4", 4)])
+BVH_NODE_DTYPE = np.dtype([("ctr", "<f4", (2, 3)), ("half", "<f4", (2, 3)), ("child", "<u4", 2),
+                           ("reserved", "<f4", 2)])
+assert OBJECT_DTYPE.itemsize == 24 and MATERIAL_DTYPE.itemsize == 20 and BVH_NODE_DTYPE.itemsize == 64
+
+# every symbol include/rtmi.h declares
+EXPORTS = ("rtmi_camera_setup", "rtmi_make_world_spheres", "rtmi_scene_create", "rtmi_scene_destroy",
+           "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_last_error", "rtmi_version",
+           "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
+           "rtmi_bvh_build")
+
+_lib = None
+
+
+class RtmiError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"rtmi error {code}: {text}")
+        self.code = code
+
+
+def lib():
+    """Load librtmi.so.  Fails loudly when the HIP extension is missing -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950) first; "
+                           "the product has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rtmi_camera_setup.argtypes = [C.POINTER(CameraParams), C.POINTER(Camera)]
+    L.rtmi_make_world_spheres.argtypes = [C.POINTER(WorldDef), vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32,
+                                          C.POINTER(C.c_uint32)]
+    L.rtmi_scene_create.argtypes = [C.POINTER(Camera), vp, C.c_uint32, vp, C.c_uint32, C.POINTER(SceneOptions),
+                                    C.POINTER(vp)]
+    L.rtmi_scene_destroy.argtypes = [vp]
+    L.rtmi_scene_destroy.restype = None
+    L.rtmi_render_rows.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]
+    L.rtmi_render_row_blocks_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp,
+                                                vp, vp]
+    L.rtmi_last_error.restype = C.c_char_p
+    L.rtmi_version.restype = C.c_char_p
+    L.rtmi_scene_get_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
+    L.rtmi_scene_get_accel.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.rtmi_scene_get_bvh.argtypes = [vp, vp, C.POINTER(C.c_uint32), vp, C.POINTER(C.c_uint32), vp,
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.rtmi_scene_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    u32p, f32p = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+    L.rtmi_bvh_build.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u32p, vp, u32p, u32p, vp, u32p, f32p, f32p]
+    for name in EXPORTS:
+        if name not in ("rtmi_last_error", "rtmi_version", "rtmi_scene_destroy"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != RTMI_OK:
+        raise RtmiError(rc, lib().rtmi_last_error().decode())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def camera_params(aspect_ratio=16.0 / 9.0, image_width=1200, samples_per_pixel=100, max_depth=50, vertical_fov=20.0,
+                  defocus_angle=0.6, focus_distance=10.0, lookfrom=(13.0, 2.0, 3.0), lookat=(0.0, 0.0, 0.0),
+                  world_up=(0.0, 1.0, 0.0)):
+    """CameraParameters of the S-RTOW workload: data/config/world.config.json:2-25 at aspect 16/9."""
+    p = CameraParams()
+    p.aspect_ratio, p.image_width = aspect_ratio, image_width
+    p.samples_per_pixel, p.max_depth = samples_per_pixel, max_depth
+    p.vertical_fov, p.defocus_angle, p.focus_distance = vertical_fov, defocus_angle, focus_distance
+    p.lookfrom[:], p.lookat[:], p.world_up[:] = lookfrom, lookat, world_up
+    return p
+
+
+def camera_setup(params):
+    cam = Camera()
+    _check(lib().rtmi_camera_setup(C.byref(params), C.byref(cam)))
+    return cam
+
+
+# the listed objects of data/config/world.config.json:43-112
+RTOW_FIXED = [
+    ((0.0, -1000.0, 0.0), 1000.0, (0, (0.5, 0.5, 0.5, 0.0))),
+    ((0.0, 1.0, 0.0), 1.0, (2, (1.5, 0.0, 0.0, 0.0))),
+    ((-4.0, 1.0, 0.0), 1.0, (0, (0.4, 0.2, 0.1, 0.0))),
+    ((4.0, 1.0, 0.0), 1.0, (0, (0.7, 0.6, 0.5, 0.0))),
+]
+
+
+def world_def(a_min=-11, a_max=11, b_min=-11, b_max=11, center_offset=(4.0, 0.2, 0.0), center_dist_treshold=0.9,
+              diffuse=0.8, metal=0.95):
+    wd = WorldDef()
+    wd.a_min, wd.a_max, wd.b_min, wd.b_max = a_min, a_max, b_min, b_max
+    wd.center_offset[:] = center_offset
+    wd.center_dist_treshold = center_dist_treshold
+    wd.diffuse_material_treshold, wd.metal_material_treshold = diffuse, metal
+    return wd
+
+
+def fixed_arrays(fixed):
+    objs = np.zeros(len(fixed), OBJECT_DTYPE)
+    mats = np.zeros(len(fixed), MATERIAL_DTYPE)
+    for i, (c, r, (k, p)) in enumerate(fixed):
+        objs[i] = (0, c, r, i)
+        mats[i] = (k, p)
+    return objs, mats
+
+
+def make_world_spheres(seed=12345, wd=None, fixed=None):
+    """S-RTOW(seed): make_world_spheres of the reference (src/ray.tracer.core.cc:99-149), RNG seeded explicitly."""
+    wd = wd or world_def()
+    fobjs, fmats = fixed_arrays(RTOW_FIXED if fixed is None else fixed)
+    cap = len(fobjs) + max(0, wd.a_max - wd.a_min) * max(0, wd.b_max - wd.b_min)
+    objs = np.zeros(cap, OBJECT_DTYPE)
+    mats = np.zeros(cap, MATERIAL_DTYPE)
+    n = C.c_uint32(0)
+    _check(lib().rtmi_make_world_spheres(C.byref(wd), _ptr(fobjs), _ptr(fmats), len(fobjs), seed, _ptr(objs),
+                                         _ptr(mats), cap, C.byref(n)))
+    return objs[:n.value].copy(), mats[:n.value].copy()
+
+
+class Scene:
+    """Owns an rtmi_scene handle (device copies of camera, world, materials, BVH)."""
+
+    def __init__(self, cam, objs, mats, accel=ACCEL_AUTO, leaf_size=0, device=-1, collect_stats=False):
+        objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
+        mats = np.ascontiguousarray(mats, dtype=MATERIAL_DTYPE)
+        opt = SceneOptions()
+        opt.struct_size = C.sizeof(SceneOptions)
+        opt.accel, opt.leaf_size, opt.device, opt.collect_stats = accel, leaf_size, device, int(collect_stats)
+        self._h = C.c_void_p()
+        self.cam = cam
+        self.width, self.height = cam.img_width, cam.img_height
+        _check(lib().rtmi_scene_create(C.byref(cam), _ptr(objs), len(objs), _ptr(mats), len(mats), C.byref(opt),
+                                       C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rtmi_scene_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def accel(self):
+        v = C.c_uint32(0)
+        _check(lib().rtmi_scene_get_accel(self._h, C.byref(v)))
+        return v.value
+
+    def render_rows(self, y0, y1, seed, rgb=True, rgba=True):
+        """rtmi_render_rows: host buffers, blocking."""
+        n = max(0, y1 - y0) * self.width
+        rgb_a = np.zeros((max(0, y1 - y0), self.width, 3), np.float32) if rgb else None
+        rgba_a = np.zeros((max(0, y1 - y0), self.width), np.uint32) if rgba else None
+        _check(lib().rtmi_render_rows(self._h, y0, y1, seed, _ptr(rgb_a) if n else None,
+                                      _ptr(rgba_a) if n else None))
+        return rgb_a, rgba_a
+
+    def render_row_blocks_device(self, y_first, block_rows, block_stride, n_blocks, seed, d_rgb=0, d_rgba=0,
+                                 stream=0):
+        """rtmi_render_row_blocks_device: raw device pointers (ints), asynchronous on `stream`."""
+        _check(lib().rtmi_render_row_blocks_device(self._h, y_first, block_rows, block_stride, n_blocks, seed,
+                                                   C.c_void_p(d_rgb or None), C.c_void_p(d_rgba or None),
+                                                   C.c_void_p(stream or None)))
+
+    def stats(self, reset=False):
+        st = Stats()
+        _check(lib().rtmi_scene_get_stats(self._h, C.byref(st), int(reset)))
+        return {n: int(getattr(st, n)) for n, _ in Stats._fields_}
+
+    def last_kernel_ms(self):
+        v = C.c_float(0)
+        _check(lib().rtmi_scene_last_kernel_ms(self._h, C.byref(v)))
+        return v.value
+
+    def bvh(self):
+        nn, ns, nc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        eps, floor = C.c_float(0), C.c_float(0)
+        _check(lib().rtmi_scene_get_bvh(self._h, None, C.byref(nn), None, C.byref(ns), None, C.byref(nc),
+                                        C.byref(eps), C.byref(floor)))
+        nodes = np.zeros(nn.value, BVH_NODE_DTYPE)
+        slots = np.zeros(ns.value, np.uint32)
+        pc = np.zeros((nc.value, 8), np.float32)
+        _check(lib().rtmi_scene_get_bvh(self._h, _ptr(nodes), None, _ptr(slots), None, _ptr(pc), None, None, None))
+        return dict(nodes=nodes, slots=slots, pad_classes=pc, pad_eps=eps.value, pad_floor=floor.value)
+
+
+def bvh_build(objs, leaf_size=0):
+    """rtmi_bvh_build: the host-side BVH of a scene (no device needed)."""
+    objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
+    n = len(objs)
+    nodes = np.zeros(max(n, 1), BVH_NODE_DTYPE)
+    slots = np.zeros(max(n, 1), np.uint32)
+    pc = np.zeros((4, 8), np.float32)
+    nn, root, depth, nc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    eps, floor = C.c_float(0), C.c_float(0)
+    _check(lib().rtmi_bvh_build(_ptr(objs), n, leaf_size, _ptr(nodes), C.byref(nn), _ptr(slots), C.byref(root),
+                                C.byref(depth), _ptr(pc), C.byref(nc), C.byref(eps), C.byref(floor)))
+    return dict(nodes=nodes[:nn.value].copy(), slots=slots[:n].copy(), pad_classes=pc[:nc.value].copy(),
+                pad_eps=eps.value, pad_floor=floor.value, root_ref=root.value, depth=depth.value)
+
+
+def row_block_shards(height, block_rows, world_size):
+    """Interleaved row-block sharding of the image plane: block b -> rank b % world_size.
+
+    Returns per rank (y_first, n_blocks, rows) with rows the number of image rows it renders; blocks of a rank are
+    `world_size` blocks apart (rtmi_render_row_blocks_device's block_stride)."""
+    n_blocks_total = (height + block_rows - 1) // block_rows
+    out = []
+    for r in range(world_size):
+        nb = (n_blocks_total - r + world_size - 1) // world_size if n_blocks_total > r else 0
+        rows = 0
+        for k in range(nb):
+            y = (r + k * world_size) * block_rows
+            rows += min(block_rows, height - y)
+        out.append((r * block_rows, nb, rows))
+    return out
+
+
+def deinterleave_rows(height, block_rows, world_size):
+    """Index map for the gathered [rank-major] slices -> scanline order.
+
+    gathered row index g (rank r's dense slice padded to `max_rows` rows, concatenated) for image row y."""
+    shards = row_block_shards(height, block_rows, world_size)
+    max_rows = max(s[2] for s in shards) if shards else 0
+    idx = np.zeros(height, np.int64)
+    for y in range(height):
+        b = y // block_rows
+        r, k = b % world_size, b // world_size
+        idx[y] = r * max_rows + k * block_rows + (y - b * block_rows)
+    return idx, max_rows

@@ -1,0 +1,936 @@
+// rtmi_device.hip -- the per-pixel path-tracing hot loop as hand-written HIP for gfx950 (CDNA4), and the
+// C-ABI entry points that need the HIP runtime.
+//
+// Replaces, from the reference (adihodos/raytracing.cpp):
+//   RayTracingCore::raytrace_pixel / get_ray / compute_color      src/ray.tracer.core.cc:218-265
+//   HittableObject_Collection::intersects / _Sphere::intersects   src/ray.tracer.object.defs.cc:11-18, 41-81
+//   Material::scatter (Lambertian / Metallic / Dielectric)        src/ray.tracer.material.defs.cc:31-109
+//   RandomNumberGenerator sampling helpers                        src/random.number.gen.hpp:11-42
+//   RGBAColor(vec3), linear_to_gamma, clamp                       src/color.hpp:9-36, src/ray.tracer.math.hpp:10-19
+//
+// Design (MI355X-first):
+//  * persistent lanes: every lane owns one pixel at a time and walks its samples in order (the reference's
+//    sequential fp32 sum, core.cc:260-263); finished lanes pull the next pixel of an 8x8-tiled index space from a
+//    global counter with one wave-aggregated atomic (ballot + prefix popcount).
+//  * recursion flattened: a lane is a small state machine FETCH -> GEN -> TRAVERSE -> SHADE; the attenuation chain
+//    A1*(A2*(...*sky)) of the recursive compute_color is replayed innermost-first at path end from a per-lane
+//    stack of material handles, so the colour is bit-identical to the recursion.
+//  * the wave leaves the traversal loop as soon as enough lanes wait for shading (ballot/popcount), shades them,
+//    refills them with their next ray and re-enters traversal: lanes never idle through a whole bounce.
+//  * scene (BVH nodes, spheres, materials) staged once per workgroup into LDS with coalesced 16-byte loads; the
+//    per-lane traversal stack lives in LDS too.
+//  * counter RNG: Philox4x32-10 keyed by seed, counter (draw block, sample, pixel): the image does not depend on
+//    tiling, row sharding or GPU count.
+//  * arithmetic of the reference path is kept operation for operation (no FMA contraction, IEEE sqrt/div); only the
+//    BVH slab tests, which the reference does not have, use FMA.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rtmi_internal.h"
+
+using namespace rtmi;
+
+// ---------------------------------------------------------------------------------------------------------
+// launch parameters (kernarg -> SGPRs)
+// ---------------------------------------------------------------------------------------------------------
+struct RtmiLaunch {
+    rtmi_camera cam;
+    // scene, global memory (staged into LDS by every workgroup)
+    const uint4* spheres;  // [n_slots] {cx, cy, cz, r*r} as bits
+    const uint4* aux;      // [n_slots] {object index, material handle, radius bits, 0}
+    const uint4* mats;     // [n_mats]  2 x uint4 per material: {kind, p0, p1, p2}, {p3, 0, 0, 0}
+    const uint4* nodes;    // [n_nodes] 4 x uint4 per node (rtmi_bvh_node)
+    uint32_t n_slots, n_mats, n_nodes, root_ref;
+    float pad_classes[kMaxPadClasses][8];
+    uint32_t n_pad_classes;
+    float pad_eps, pad_floor;
+    // LDS carve-up (byte offsets)
+    uint32_t lds_spheres, lds_aux, lds_mats, lds_nodes, lds_stack, stack_depth;
+    // image rows handled by this launch
+    uint32_t y_first, block_rows, block_stride, n_local_rows;
+    uint32_t tiles_x, n_work; // work index space = tiles * 64
+    uint32_t wait_thresh;     // leave the traversal loop when this many lanes of a wave wait for shading
+    uint64_t seed;
+    float* out_rgb;
+    uint32_t* out_rgba;
+    uint32_t* work_counter;
+    uint32_t* att_stack; // [maxdepth][total_lanes] material handles of the non-dielectric bounces of the live path
+    unsigned long long* stats; // {samples, segments, sphere_tests, node_tests}
+};
+
+#define DEV static __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------------------
+// vec3 with glm's published semantics (glm is an un-vendored dependency of the reference)
+// ---------------------------------------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+DEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+DEV V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV V3 vmul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEV V3 vscale(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+DEV V3 vdivs(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+DEV V3 vneg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+DEV float vdot(V3 a, V3 b) { // glm::dot: t = a*b; t.x + t.y + t.z
+    const float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+    return (tx + ty) + tz;
+}
+DEV V3 vnormalize(V3 v) { return vscale(v, 1.0f / __builtin_sqrtf(vdot(v, v))); } // v * inversesqrt(dot(v,v))
+DEV V3 vreflect(V3 I, V3 N) { return vsub(I, vscale(vscale(N, vdot(N, I)), 2.0f)); }
+DEV V3 vrefract(V3 I, V3 N, float eta) {
+    const float d = vdot(N, I);
+    const float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k >= 0.0f) return vsub(vscale(I, eta), vscale(N, eta * d + __builtin_sqrtf(k)));
+    return mk(0.0f, 0.0f, 0.0f);
+}
+DEV V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------------------------------------------------
+// counter RNG: draw #k of (seed, pixel, sample) = word (k & 3) of Philox4x32-10({k >> 2, sample, pixel, 0}, seed);
+// random_double() = u32 * 2^-32.  The affine maps of random.number.gen.hpp are exact in double for a 32-bit
+// draw, so the double -> float narrowing of the reference equals one int -> float conversion here.
+// ---------------------------------------------------------------------------------------------------------
+struct Rng {
+    uint32_t k, pixel, sample;
+    uint32_t w0, w1, w2, w3;
+};
+
+DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, Rng& r) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    r.w0 = c0; r.w1 = c1; r.w2 = c2; r.w3 = c3;
+}
+
+DEV uint32_t rng_u32(Rng& r, uint64_t seed) {
+    const uint32_t k = r.k++;
+    const uint32_t j = k & 3u;
+    if (j == 0u) philox4x32_10(k >> 2, r.sample, r.pixel, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return j == 0u ? r.w0 : (j == 1u ? r.w1 : (j == 2u ? r.w2 : r.w3));
+}
+// (float)(random_double() - 0.5f)   [sample_square, random.number.gen.hpp:16]:  (u - 2^31) * 2^-32, exact in double
+DEV float draw_centered(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 2.3283064365386963e-10f; }
+// (float)random_double(-1, 1)       [random.number.gen.hpp:12-14]:  -1 + 2u*2^-32 = (u - 2^31) * 2^-31, exact in double
+DEV float draw_pm1(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 4.6566128730773926e-10f; }
+
+// random_unit_vector, random.number.gen.hpp:21-29 (`> 1e-160` on a float is `> 0`)
+DEV V3 random_unit_vector(Rng& r, uint64_t seed) {
+    for (;;) {
+        const float x = draw_pm1(rng_u32(r, seed));
+        const float y = draw_pm1(rng_u32(r, seed));
+        const float z = draw_pm1(rng_u32(r, seed));
+        const V3 p = mk(x, y, z);
+        const float l2 = vdot(p, p);
+        if (l2 > 0.0f && l2 <= 1.0f) return vdivs(p, __builtin_sqrtf(l2));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// lane state machine
+// ---------------------------------------------------------------------------------------------------------
+enum : uint32_t { PH_FETCH = 0, PH_GEN = 1, PH_TRAV = 2, PH_SHADE = 3, PH_DONE = 4 };
+
+struct Trav { // per-segment traversal state
+    V3 o, d;
+    float a;          // dot(d, d), object.defs.cc:44
+    float tbest;      // closest accepted root so far (Interval::Max, object.defs.cc:69)
+    uint32_t best;    // slot of the closest sphere, ~0u = none
+    uint32_t bestobj; // its object index (tie rule: first inserted wins, object.defs.cc:73)
+    uint32_t cur;     // BVH: current node/leaf reference; brute force: unused
+    uint32_t sp;      // BVH: stack entries
+    V3 inv, oinv, pinv; // BVH slab test: 1/d, -o/d, pad*|1/d|
+};
+
+DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// HittableObject_Sphere::intersects candidate root (object.defs.cc:41-60): root1 if it is beyond tmin, else root2.
+// Acceptance against the shrinking Max is done by the caller.  sph = {C, R*R}.
+DEV void sphere_test(const float4 sph, const Trav& t, uint32_t slot, uint32_t obj_or_slot, bool slot_is_obj,
+                     const uint4* lds_aux, float& tbest, uint32_t& best, uint32_t& bestobj) {
+    const V3 oc = mk(sph.x - t.o.x, sph.y - t.o.y, sph.z - t.o.z);
+    const float h = vdot(t.d, oc);
+    const float c = vdot(oc, oc) - sph.w;
+    const float delta = h * h - t.a * c;
+    if (delta >= 0.0f) {
+        const float sqrtd = __builtin_sqrtf(delta);
+        float root = (h - sqrtd) / t.a;
+        if (!(root > 0.0001f)) root = (h + sqrtd) / t.a; // Interval{0.0001, .}.surrounds, interval.hpp:14
+        if (root > 0.0001f) {
+            if (root < tbest) {
+                tbest = root;
+                best = slot;
+                bestobj = slot_is_obj ? obj_or_slot : lds_aux[slot].x;
+            } else if (!slot_is_obj && root == tbest) {
+                const uint32_t obj = lds_aux[slot].x;
+                if (obj < bestobj) {
+                    best = slot;
+                    bestobj = obj;
+                }
+            }
+        }
+    }
+}
+
+template <int ACCEL, bool STATS>
+__global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    // ---- stage the scene into LDS: coalesced 16-byte loads, one pass per array -----------------------------
+    uint4* lds_spheres = reinterpret_cast<uint4*>(lds_raw + P.lds_spheres);
+    uint4* lds_aux = reinterpret_cast<uint4*>(lds_raw + P.lds_aux);
+    uint4* lds_mats = reinterpret_cast<uint4*>(lds_raw + P.lds_mats);
+    uint4* lds_nodes = reinterpret_cast<uint4*>(lds_raw + P.lds_nodes);
+    uint16_t* lds_stack = reinterpret_cast<uint16_t*>(lds_raw + P.lds_stack);
+    for (uint32_t i = threadIdx.x; i < P.n_slots; i += blockDim.x) {
+        lds_spheres[i] = P.spheres[i];
+        lds_aux[i] = P.aux[i];
+    }
+    for (uint32_t i = threadIdx.x; i < 2u * P.n_mats; i += blockDim.x) lds_mats[i] = P.mats[i];
+    if (ACCEL == RTMI_ACCEL_BVH) {
+        for (uint32_t i = threadIdx.x; i < 4u * P.n_nodes; i += blockDim.x) lds_nodes[i] = P.nodes[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = lane_id();
+    const uint32_t total_lanes = gridDim.x * blockDim.x;
+    const uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t W = P.cam.img_width;
+    const uint32_t spp = P.cam.samples_per_pixel;
+
+    uint32_t phase = PH_FETCH;
+    uint32_t px = 0, ply = 0, s = 0, depth_left = 0, natt = 0;
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    Rng rng{};
+    Trav t{};
+    uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0;
+
+    auto begin_segment = [&](V3 o, V3 d) {
+        t.o = o;
+        t.d = d;
+        t.a = vdot(d, d);
+        t.tbest = __builtin_inff();
+        t.best = ~0u;
+        t.bestobj = ~0u;
+        t.sp = 0;
+        if (ACCEL == RTMI_ACCEL_BVH) {
+            t.cur = P.root_ref;
+            t.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+            float pad = P.pad_floor;
+            for (uint32_t c = 0; c < P.n_pad_classes; ++c) {
+                const float* k = P.pad_classes[c];
+                const float ax = fmaxf((o.x - k[0]) * (o.x - k[0]), (k[3] - o.x) * (k[3] - o.x));
+                const float ay = fmaxf((o.y - k[1]) * (o.y - k[1]), (k[4] - o.y) * (k[4] - o.y));
+                const float az = fmaxf((o.z - k[2]) * (o.z - k[2]), (k[5] - o.z) * (k[5] - o.z));
+                pad = fmaxf(pad, (P.pad_eps * ((ax + ay) + az)) * k[6]);
+            }
+            t.oinv = mk(-(o.x * t.inv.x), -(o.y * t.inv.y), -(o.z * t.inv.z));
+            t.pinv = mk(pad * __builtin_fabsf(t.inv.x), pad * __builtin_fabsf(t.inv.y), pad * __builtin_fabsf(t.inv.z));
+        } else {
+            t.cur = 0; // next sphere of the linear scan
+        }
+        if (STATS) st_segments++;
+    };
+
+    for (;;) {
+        // ---- FETCH: one wave-aggregated atomic hands out consecutive indices of the 8x8-tiled pixel space -----
+        while (phase == PH_FETCH) {
+            const uint64_t need = __ballot(1);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            uint32_t base = 0;
+            if (rank == 0) base = atomicAdd(P.work_counter, (uint32_t)__popcll(need));
+            base = __shfl(base, __ffsll((long long)need) - 1);
+            const uint32_t idx = base + rank;
+            if (idx >= P.n_work) {
+                phase = PH_DONE;
+            } else {
+                const uint32_t tile = idx >> 6, j = idx & 63u;
+                const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+                px = tx * 8u + (j & 7u);
+                ply = ty * 8u + (j >> 3);
+                if (px < W && ply < P.n_local_rows) {
+                    s = 0;
+                    sum = mk(0.0f, 0.0f, 0.0f);
+                    phase = PH_GEN;
+                }
+            }
+        }
+        if (__ballot(phase != PH_DONE) == 0ull) break;
+
+        // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
+        if (phase == PH_GEN) {
+            const uint32_t blk = ply / P.block_rows;
+            const uint32_t gy = P.y_first + blk * P.block_stride * P.block_rows + (ply - blk * P.block_rows);
+            rng.k = 0;
+            rng.sample = s;
+            rng.pixel = gy * W + px;
+            const float offx = draw_centered(rng_u32(rng, P.seed));
+            const float offy = draw_centered(rng_u32(rng, P.seed));
+            const V3 du = ld3(P.cam.pixel_delta_u), dv = ld3(P.cam.pixel_delta_v);
+            const V3 pixel_sample =
+                vadd(vadd(ld3(P.cam.pixel00), vscale(du, (float)px + offx)), vscale(dv, (float)gy + offy));
+            V3 origin = ld3(P.cam.cam_center);
+            if (!(P.cam.defocus_angle <= 0.0f)) {
+                // random_vector_on_unit_disk, random.number.gen.hpp:35-42
+                float dx, dy;
+                for (;;) {
+                    dx = draw_pm1(rng_u32(rng, P.seed));
+                    dy = draw_pm1(rng_u32(rng, P.seed));
+                    if (vdot(mk(dx, dy, 0.0f), mk(dx, dy, 0.0f)) < 1.0f) break;
+                }
+                origin = vadd(vadd(ld3(P.cam.cam_center), vscale(ld3(P.cam.defocus_disk_u), dx)),
+                              vscale(ld3(P.cam.defocus_disk_v), dy));
+            }
+            depth_left = P.cam.maxdepth;
+            natt = 0;
+            if (depth_left == 0) {
+                // compute_color(depth == 0) returns 0 at once (core.cc:238-240): the sample is black
+                t.cur = 0xfffffffeu; // marker read by SHADE: finish the sample without tracing
+                t.best = ~0u;
+                phase = PH_SHADE;
+            } else {
+                begin_segment(origin, vsub(pixel_sample, origin));
+                phase = PH_TRAV;
+            }
+        }
+
+        // ---- TRAVERSE ---------------------------------------------------------------------------------------------
+        if (ACCEL == RTMI_ACCEL_BVH) {
+            for (;;) {
+                const uint64_t trav = __ballot(phase == PH_TRAV);
+                if (trav == 0ull) break;
+                const uint32_t nwait = (uint32_t)__popcll(__ballot(phase == PH_SHADE));
+                if (nwait >= P.wait_thresh) break;
+                if (phase == PH_TRAV) {
+                    bool pop = false;
+                    if (t.cur & kLeafBit) {
+                        const uint32_t first = t.cur & 0x00ffffffu, cnt = (t.cur >> 24) & 0x7fu;
+                        for (uint32_t q = 0; q < cnt; ++q) {
+                            const uint4 raw = lds_spheres[first + q];
+                            const float4 sph = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y),
+                                                           __uint_as_float(raw.z), __uint_as_float(raw.w));
+                            sphere_test(sph, t, first + q, 0u, false, lds_aux, t.tbest, t.best, t.bestobj);
+                        }
+                        if (STATS) st_sphere += cnt;
+                        pop = true;
+                    } else {
+                        const uint4 n0 = lds_nodes[4u * t.cur + 0u];
+                        const uint4 n1 = lds_nodes[4u * t.cur + 1u];
+                        const uint4 n2 = lds_nodes[4u * t.cur + 2u];
+                        const uint4 n3 = lds_nodes[4u * t.cur + 3u];
+                        // rtmi_bvh_node: ctr[2][3] | half[2][3] | child[2] | reserved[2]
+                        const float c0x = __uint_as_float(n0.x), c0y = __uint_as_float(n0.y), c0z = __uint_as_float(n0.z);
+                        const float c1x = __uint_as_float(n0.w), c1y = __uint_as_float(n1.x), c1z = __uint_as_float(n1.y);
+                        const float h0x = __uint_as_float(n1.z), h0y = __uint_as_float(n1.w), h0z = __uint_as_float(n2.x);
+                        const float h1x = __uint_as_float(n2.y), h1y = __uint_as_float(n2.z), h1z = __uint_as_float(n2.w);
+                        const float ax = __builtin_fabsf(t.inv.x), ay = __builtin_fabsf(t.inv.y), az = __builtin_fabsf(t.inv.z);
+                        // slab test in centre/half form: the pad rides in the FMA of the half extent
+                        const float tc0x = __builtin_fmaf(c0x, t.inv.x, t.oinv.x), th0x = __builtin_fmaf(h0x, ax, t.pinv.x);
+                        const float tc0y = __builtin_fmaf(c0y, t.inv.y, t.oinv.y), th0y = __builtin_fmaf(h0y, ay, t.pinv.y);
+                        const float tc0z = __builtin_fmaf(c0z, t.inv.z, t.oinv.z), th0z = __builtin_fmaf(h0z, az, t.pinv.z);
+                        const float tc1x = __builtin_fmaf(c1x, t.inv.x, t.oinv.x), th1x = __builtin_fmaf(h1x, ax, t.pinv.x);
+                        const float tc1y = __builtin_fmaf(c1y, t.inv.y, t.oinv.y), th1y = __builtin_fmaf(h1y, ay, t.pinv.y);
+                        const float tc1z = __builtin_fmaf(c1z, t.inv.z, t.oinv.z), th1z = __builtin_fmaf(h1z, az, t.pinv.z);
+                        // fmaxf/fminf drop a NaN operand (0 * inf on an axis-parallel ray), which keeps the test conservative
+                        const float tn0 = fmaxf(fmaxf(tc0x - th0x, tc0y - th0y), fmaxf(tc0z - th0z, 0.0001f));
+                        const float tf0 = fminf(fminf(tc0x + th0x, tc0y + th0y), fminf(tc0z + th0z, t.tbest));
+                        const float tn1 = fmaxf(fmaxf(tc1x - th1x, tc1y - th1y), fmaxf(tc1z - th1z, 0.0001f));
+                        const float tf1 = fminf(fminf(tc1x + th1x, tc1y + th1y), fminf(tc1z + th1z, t.tbest));
+                        if (STATS) st_node += 2;
+                        const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
+                        const uint32_t ch0 = n3.x, ch1 = n3.y;
+                        if (hit0 && hit1) {
+                            const bool swap = tn1 < tn0;
+                            const uint32_t far_ref = swap ? ch0 : ch1;
+                            // stack entry: node index, or leaf as 0x8000 | (count-1) << 13 | first slot
+                            const uint32_t packed = (far_ref & kLeafBit)
+                                ? (0x8000u | ((((far_ref >> 24) & 0x7fu) - 1u) << 13) | (far_ref & 0x1fffu))
+                                : far_ref;
+                            lds_stack[t.sp * blockDim.x + threadIdx.x] = (uint16_t)packed;
+                            t.sp++;
+                            t.cur = swap ? ch1 : ch0;
+                        } else if (hit0) {
+                            t.cur = ch0;
+                        } else if (hit1) {
+                            t.cur = ch1;
+                        } else {
+                            pop = true;
+                        }
+                    }
+                    if (pop) {
+                        if (t.sp == 0) {
+                            phase = PH_SHADE;
+                        } else {
+                            t.sp--;
+                            const uint32_t packed = lds_stack[t.sp * blockDim.x + threadIdx.x];
+                            t.cur = (packed & 0x8000u)
+                                ? (kLeafBit | ((((packed >> 13) & 3u) + 1u) << 24) | (packed & 0x1fffu))
+                                : packed;
+                        }
+                    }
+                }
+            }
+        } else {
+            // the reference's linear closest-hit scan (object.defs.cc:68-81); all lanes of a wave read the same
+            // sphere, so every LDS read is a broadcast.
+            if (__ballot(phase == PH_TRAV) != 0ull) {
+                if (phase == PH_TRAV) {
+                    for (uint32_t i = 0; i < P.n_slots; ++i) {
+                        const uint4 raw = lds_spheres[i];
+                        const float4 sph = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y),
+                                                       __uint_as_float(raw.z), __uint_as_float(raw.w));
+                        sphere_test(sph, t, i, i, true, lds_aux, t.tbest, t.best, t.bestobj);
+                    }
+                    if (STATS) st_sphere += P.n_slots;
+                    phase = PH_SHADE;
+                }
+            }
+        }
+
+        // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
+        if (phase == PH_SHADE) {
+            bool ended = false;
+            V3 color = mk(0.0f, 0.0f, 0.0f);
+            if (t.cur == 0xfffffffeu) {
+                ended = true; // maxdepth == 0: black sample
+            } else if (t.best != ~0u) {
+                // IntersectionRecord for the winning sphere, object.defs.cc:62-65 and :11-18
+                const uint4 sraw = lds_spheres[t.best];
+                const uint4 araw = lds_aux[t.best];
+                const V3 C = mk(__uint_as_float(sraw.x), __uint_as_float(sraw.y), __uint_as_float(sraw.z));
+                const float R = __uint_as_float(araw.z);
+                const V3 p = vadd(t.o, vscale(t.d, t.tbest)); // Ray::point_at_param, ray.hpp:9
+                const V3 outward = vdivs(vsub(p, C), R);
+                const bool front = vdot(t.d, outward) < 0.0f;
+                const V3 N = front ? outward : vneg(outward);
+                const uint32_t mh = araw.y;
+                const uint4 m0 = lds_mats[2u * mh], m1 = lds_mats[2u * mh + 1u];
+                const uint32_t kind = m0.x;
+                const V3 albedo = mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w));
+                V3 sd = mk(0.0f, 0.0f, 0.0f);
+                bool scattered = true;
+                if (kind == 0u) { // Material_Lambertian::scatter, material.defs.cc:31-42
+                    sd = vadd(N, random_unit_vector(rng, P.seed));
+                    const float eps = 1e-8f; // near_zero, ray.tracer.math.hpp:16-19
+                    if (__builtin_fabsf(sd.x) < eps && __builtin_fabsf(sd.y) < eps && __builtin_fabsf(sd.z) < eps) sd = N;
+                } else if (kind == 1u) { // Material_Metallic::scatter, material.defs.cc:44-55
+                    const float fuzz = __uint_as_float(m1.x);
+                    V3 refl = vreflect(t.d, N);
+                    refl = vadd(vnormalize(refl), vscale(random_unit_vector(rng, P.seed), fuzz));
+                    scattered = vdot(refl, N) > 0.0f;
+                    sd = refl;
+                } else { // Material_Dielectric::scatter, material.defs.cc:57-87
+                    const float ri = __uint_as_float(m0.y);
+                    const float eta = front ? (1.0f / ri) : ri;
+                    const V3 unit_dir = vnormalize(t.d);
+                    const float cos_theta = fminf(vdot(vneg(unit_dir), N), 1.0f);
+                    const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+                    bool reflect_it = (eta * sin_theta) > 1.0f;
+                    if (!reflect_it) { // short-circuit ||: the draw happens only when refraction is possible
+                        const float r0 = (1.0f - eta) / (1.0f + eta);
+                        const float r1 = r0 * r0;
+                        // powf(x, 5): x^5 through double is the correctly rounded value except for ties
+                        const double xd = (double)(1.0f - cos_theta);
+                        const double x2 = xd * xd;
+                        const float p5 = (float)((x2 * x2) * xd);
+                        const float schlick = r1 + (1.0f - r1) * p5;
+                        const double u = (double)rng_u32(rng, P.seed) * 2.3283064365386963e-10;
+                        reflect_it = (double)schlick > u;
+                    }
+                    sd = reflect_it ? vreflect(unit_dir, N) : vrefract(unit_dir, N, eta);
+                }
+                if (!scattered) {
+                    ended = true; // absorbed: compute_color returns 0 (core.cc:251)
+                } else {
+                    if (kind != 2u) { // dielectric attenuation is (1,1,1): multiplying by it is exact, skip
+                        P.att_stack[(size_t)natt * total_lanes + glane] = mh;
+                        natt++;
+                    }
+                    depth_left--;
+                    if (depth_left == 0) {
+                        ended = true; // the next compute_color call returns 0 (core.cc:238-240)
+                    } else {
+                        begin_segment(p, sd);
+                        phase = PH_TRAV;
+                    }
+                }
+            } else {
+                // miss: sky gradient (core.cc:254-256), then the attenuations innermost-first (core.cc:247-248)
+                const V3 unit_dir = vnormalize(t.d);
+                const float tt = 0.5f * (unit_dir.y + 1.0f);
+                color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
+                for (uint32_t q = natt; q-- > 0u;) {
+                    const uint32_t mh = P.att_stack[(size_t)q * total_lanes + glane];
+                    const uint4 m0 = lds_mats[2u * mh];
+                    color = vmul(mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w)), color);
+                }
+                ended = true;
+            }
+            if (ended) {
+                // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
+                sum = vadd(sum, color);
+                s++;
+                if (STATS) st_samples++;
+                if (s >= spp) {
+                    const V3 outc = vscale(sum, P.cam.pixels_sample_scale);
+                    const size_t o = (size_t)ply * W + px;
+                    if (P.out_rgb) {
+                        P.out_rgb[3 * o + 0] = outc.x;
+                        P.out_rgb[3 * o + 1] = outc.y;
+                        P.out_rgb[3 * o + 2] = outc.z;
+                    }
+                    if (P.out_rgba) {
+                        // RGBAColor(vec3), color.hpp:30-36
+                        auto ch = [](float v) -> uint32_t {
+                            const float g = v > 0.0f ? __builtin_sqrtf(v) : 0.0f;
+                            const float c = g < 0.0f ? 0.0f : (g > 0.999f ? 0.999f : g);
+                            return (uint32_t)(uint8_t)(c * 256.0f);
+                        };
+                        P.out_rgba[o] = ch(outc.x) | (ch(outc.y) << 8) | (ch(outc.z) << 16) | (255u << 24);
+                    }
+                    phase = PH_FETCH;
+                } else {
+                    phase = PH_GEN;
+                }
+            }
+        }
+    }
+
+    if (STATS) {
+        atomicAdd(&P.stats[0], (unsigned long long)st_samples);
+        atomicAdd(&P.stats[1], (unsigned long long)st_segments);
+        atomicAdd(&P.stats[2], (unsigned long long)st_sphere);
+        atomicAdd(&P.stats[3], (unsigned long long)st_node);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side of the C-ABI
+// ---------------------------------------------------------------------------------------------------------
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                                    \
+            return e_ == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_HIP;                                  \
+        }                                                                                                    \
+    } while (0)
+
+struct rtmi_scene {
+    rtmi_camera cam{};
+    int device = 0;
+    uint32_t accel = RTMI_ACCEL_BVH;
+    bool collect_stats = false;
+    uint32_t n_objects = 0, n_mats = 0;
+    Bvh bvh;
+    // device buffers
+    uint4* d_spheres = nullptr;
+    uint4* d_aux = nullptr;
+    uint4* d_mats = nullptr;
+    uint4* d_nodes = nullptr;
+    uint32_t* d_counter = nullptr;
+    uint32_t* d_att = nullptr;
+    unsigned long long* d_stats = nullptr;
+    float* d_rgb = nullptr;     // staging for rtmi_render_rows (host-pointer entry)
+    uint32_t* d_rgba = nullptr; // staging
+    size_t staging_pixels = 0;
+    // launch geometry
+    uint32_t block = 512, grid = 0, lds_bytes = 0, stack_depth = 0;
+    uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
+    uint32_t wait_thresh = 24;
+    hipStream_t stream = nullptr; // private stream of the blocking entry point
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    std::mutex mu;
+};
+
+namespace {
+
+using KernelFn = void (*)(const RtmiLaunch);
+
+KernelFn pick_kernel(uint32_t accel, bool stats) {
+    if (accel == RTMI_ACCEL_BVH) return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false>;
+    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BRUTE, true> : rtmi_trace_kernel<RTMI_ACCEL_BRUTE, false>;
+}
+
+void free_scene(rtmi_scene* s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    hipFree(s->d_spheres);
+    hipFree(s->d_aux);
+    hipFree(s->d_mats);
+    hipFree(s->d_nodes);
+    hipFree(s->d_counter);
+    hipFree(s->d_att);
+    hipFree(s->d_stats);
+    hipFree(s->d_rgb);
+    hipFree(s->d_rgba);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks,
+           uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream) {
+    const uint32_t H = s->cam.img_height, W = s->cam.img_width;
+    if (block_rows == 0 || block_stride == 0) {
+        set_error("rtmi: block_rows and block_stride must be positive");
+        return RTMI_ERR_BAD_ARG;
+    }
+    // every block must start inside the image; the last one may be clipped
+    uint32_t n_local_rows = 0;
+    for (uint32_t k = 0; k < n_blocks; ++k) {
+        const uint64_t y = (uint64_t)y_first + (uint64_t)k * block_stride * block_rows;
+        if (y >= H) {
+            set_error("rtmi: row block starts outside the image");
+            return RTMI_ERR_BAD_ARG;
+        }
+        n_local_rows += (uint32_t)std::min<uint64_t>(block_rows, H - y);
+        if (y + block_rows > H && k + 1 != n_blocks) {
+            set_error("rtmi: only the last row block may be clipped");
+            return RTMI_ERR_BAD_ARG;
+        }
+    }
+    if (n_local_rows == 0 || W == 0) return RTMI_OK;
+
+    RtmiLaunch P{};
+    P.cam = s->cam;
+    P.spheres = s->d_spheres;
+    P.aux = s->d_aux;
+    P.mats = s->d_mats;
+    P.nodes = s->d_nodes;
+    P.n_slots = s->n_objects;
+    P.n_mats = s->n_mats;
+    P.n_nodes = (uint32_t)s->bvh.nodes.size();
+    P.root_ref = s->bvh.root_ref;
+    std::memcpy(P.pad_classes, s->bvh.pad_classes, sizeof(P.pad_classes));
+    P.n_pad_classes = s->bvh.n_pad_classes;
+    P.pad_eps = s->bvh.pad_eps;
+    P.pad_floor = s->bvh.pad_floor;
+    P.lds_spheres = s->lds_spheres;
+    P.lds_aux = s->lds_aux;
+    P.lds_mats = s->lds_mats;
+    P.lds_nodes = s->lds_nodes;
+    P.lds_stack = s->lds_stack;
+    P.stack_depth = s->stack_depth;
+    P.y_first = y_first;
+    P.block_rows = block_rows;
+    P.block_stride = block_stride;
+    P.n_local_rows = n_local_rows;
+    P.tiles_x = (W + 7u) / 8u;
+    const uint64_t n_work = (uint64_t)P.tiles_x * ((n_local_rows + 7u) / 8u) * 64u;
+    if (n_work > 0xffffffffull) {
+        set_error("rtmi: image too large for one launch");
+        return RTMI_ERR_UNSUPPORTED;
+    }
+    P.n_work = (uint32_t)n_work;
+    P.wait_thresh = s->wait_thresh;
+    P.seed = seed;
+    P.out_rgb = d_rgb;
+    P.out_rgba = d_rgba;
+    P.work_counter = s->d_counter;
+    P.att_stack = s->d_att;
+    P.stats = s->d_stats;
+
+    HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipEventRecord(s->ev0, stream));
+    KernelFn fn = pick_kernel(s->accel, s->collect_stats);
+    void* args[] = {&P};
+    HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
+    HIP_TRY(hipEventRecord(s->ev1, stream));
+    s->ev_valid = true;
+    return RTMI_OK;
+}
+
+} // namespace
+
+extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
+                                 const rtmi_material* materials, uint32_t n_materials,
+                                 const rtmi_scene_options* options, rtmi_scene** out) {
+    if (!camera || !out || (n_objects && !objects) || (n_materials && !materials)) {
+        set_error("rtmi_scene_create: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    *out = nullptr;
+    if (camera->samples_per_pixel == 0) {
+        set_error("rtmi_scene_create: samples_per_pixel must be at least 1");
+        return RTMI_ERR_BAD_ARG;
+    }
+    for (uint32_t i = 0; i < n_objects; ++i) {
+        if (objects[i].kind != 0u) {
+            set_error("rtmi_scene_create: unknown HittableObjectKind (only Sphere = 0 exists)");
+            return RTMI_ERR_BAD_ARG;
+        }
+        if (objects[i].material >= n_materials) { // the reference asserts this, material.defs.hpp:104
+            set_error("rtmi_scene_create: object refers to a material handle outside the collection");
+            return RTMI_ERR_BAD_ARG;
+        }
+    }
+    for (uint32_t i = 0; i < n_materials; ++i) {
+        if (materials[i].kind > 2u) {
+            set_error("rtmi_scene_create: unknown MaterialKind");
+            return RTMI_ERR_BAD_ARG;
+        }
+    }
+    rtmi_scene_options opt{};
+    if (options) std::memcpy(&opt, options, std::min<size_t>(sizeof(opt), options->struct_size));
+
+    rtmi_scene* s = new (std::nothrow) rtmi_scene();
+    if (!s) {
+        set_error("rtmi_scene_create: out of host memory");
+        return RTMI_ERR_OOM;
+    }
+    auto fail = [&](int rc) {
+        free_scene(s);
+        return rc;
+    };
+#define HIP_TRY_S(expr)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                \
+            return fail(e_ == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_HIP);        \
+        }                                                                                \
+    } while (0)
+
+    int dev = opt.device;
+    if (dev < 0) HIP_TRY_S(hipGetDevice(&dev));
+    HIP_TRY_S(hipSetDevice(dev));
+    s->device = dev;
+    s->cam = *camera;
+    s->collect_stats = opt.collect_stats != 0;
+    s->n_objects = n_objects;
+    s->n_mats = n_materials;
+    s->accel = opt.accel == RTMI_ACCEL_AUTO ? (n_objects > 8 ? RTMI_ACCEL_BVH : RTMI_ACCEL_BRUTE) : opt.accel;
+    if (s->accel != RTMI_ACCEL_BVH && s->accel != RTMI_ACCEL_BRUTE) {
+        set_error("rtmi_scene_create: unknown accel");
+        return fail(RTMI_ERR_BAD_ARG);
+    }
+
+    // slot order: leaf order for the BVH, insertion order for the linear scan
+    std::vector<uint32_t> slot_object(n_objects);
+    if (s->accel == RTMI_ACCEL_BVH) {
+        build_bvh(objects, n_objects, opt.leaf_size ? opt.leaf_size : 2u, s->bvh);
+        slot_object = s->bvh.slot_object;
+        if (s->bvh.nodes.size() >= 0x8000u || n_objects > 0x2000u) {
+            set_error("rtmi_scene_create: scene too large for the LDS-resident BVH kernel (max 8192 spheres)");
+            return fail(RTMI_ERR_UNSUPPORTED);
+        }
+    } else {
+        for (uint32_t i = 0; i < n_objects; ++i) slot_object[i] = i;
+        s->bvh.root_ref = 0;
+    }
+    std::vector<uint4> h_spheres(n_objects), h_aux(n_objects), h_mats(2 * (size_t)n_materials);
+    auto fbits = [](float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        return u;
+    };
+    for (uint32_t i = 0; i < n_objects; ++i) {
+        const rtmi_object& o = objects[slot_object[i]];
+        // Radius * Radius of object.defs.cc:46 is the same float for every ray: computed once here
+        const float r2 = o.radius * o.radius;
+        h_spheres[i] = make_uint4(fbits(o.center[0]), fbits(o.center[1]), fbits(o.center[2]), fbits(r2));
+        h_aux[i] = make_uint4(slot_object[i], o.material, fbits(o.radius), 0u);
+    }
+    for (uint32_t i = 0; i < n_materials; ++i) {
+        const rtmi_material& m = materials[i];
+        h_mats[2 * i] = make_uint4(m.kind, fbits(m.p[0]), fbits(m.p[1]), fbits(m.p[2]));
+        h_mats[2 * i + 1] = make_uint4(fbits(m.p[3]), 0u, 0u, 0u);
+    }
+
+    // LDS carve-up
+    auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+    uint32_t off = 0;
+    s->lds_nodes = off;
+    off += (uint32_t)s->bvh.nodes.size() * 64u;
+    s->lds_spheres = off;
+    off += n_objects * 16u;
+    s->lds_aux = off;
+    off += n_objects * 16u;
+    s->lds_mats = off;
+    off += n_materials * 32u;
+    off = align16(off);
+    s->lds_stack = off;
+    s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) : 0u;
+    off += s->stack_depth * s->block * 2u;
+    s->lds_bytes = align16(off);
+    if (s->lds_bytes > 160u * 1024u) {
+        set_error("rtmi_scene_create: scene does not fit the 160 KiB LDS of a CU");
+        return fail(RTMI_ERR_UNSUPPORTED);
+    }
+
+    auto upload = [&](uint4** dptr, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIP_TRY_S(upload(&s->d_spheres, h_spheres.data(), h_spheres.size() * sizeof(uint4)));
+    HIP_TRY_S(upload(&s->d_aux, h_aux.data(), h_aux.size() * sizeof(uint4)));
+    HIP_TRY_S(upload(&s->d_mats, h_mats.data(), h_mats.size() * sizeof(uint4)));
+    HIP_TRY_S(upload(&s->d_nodes, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(rtmi_bvh_node)));
+
+    // persistent grid: exactly as many workgroups as the device keeps resident
+    KernelFn fn = pick_kernel(s->accel, s->collect_stats);
+    HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)s->lds_bytes));
+    int per_cu = 0;
+    HIP_TRY_S(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)s->block, s->lds_bytes));
+    if (per_cu < 1) {
+        set_error("rtmi_scene_create: kernel cannot be resident with this scene");
+        return fail(RTMI_ERR_UNSUPPORTED);
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY_S(hipGetDeviceProperties(&prop, dev));
+    if (const char* e = std::getenv("RTMI_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));
+    if (const char* e = std::getenv("RTMI_WAIT_THRESH")) s->wait_thresh = (uint32_t)std::max(1, std::atoi(e));
+    s->grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+
+    HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_counter), 16));
+    HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 4 * sizeof(unsigned long long)));
+    HIP_TRY_S(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
+    const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * s->grid * s->block * sizeof(uint32_t));
+    HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_att), att_bytes));
+    HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY_S(hipEventCreate(&s->ev0));
+    HIP_TRY_S(hipEventCreate(&s->ev1));
+#undef HIP_TRY_S
+    *out = s;
+    return RTMI_OK;
+}
+
+extern "C" void rtmi_scene_destroy(rtmi_scene* scene) { free_scene(scene); }
+
+extern "C" int rtmi_render_row_blocks_device(rtmi_scene* s, uint32_t y_first, uint32_t block_rows,
+                                             uint32_t block_stride, uint32_t n_blocks, uint64_t seed,
+                                             void* d_rgb_linear_out, void* d_rgba8_out, void* hip_stream) {
+    if (!s) {
+        set_error("rtmi_render_row_blocks_device: null scene");
+        return RTMI_ERR_BAD_ARG;
+    }
+    std::lock_guard<std::mutex> lock(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    return launch(s, y_first, block_rows, block_stride, n_blocks, seed, static_cast<float*>(d_rgb_linear_out),
+                  static_cast<uint32_t*>(d_rgba8_out), static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int rtmi_render_rows(rtmi_scene* s, uint32_t y0, uint32_t y1, uint64_t seed, float* rgb_linear_out,
+                                uint32_t* rgba8_out) {
+    if (!s) {
+        set_error("rtmi_render_rows: null scene");
+        return RTMI_ERR_BAD_ARG;
+    }
+    if (y0 > y1 || y1 > s->cam.img_height) {
+        set_error("rtmi_render_rows: rows outside the image");
+        return RTMI_ERR_BAD_ARG;
+    }
+    if (y0 == y1) return RTMI_OK;
+    std::lock_guard<std::mutex> lock(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t pixels = (size_t)(y1 - y0) * s->cam.img_width;
+    if (pixels > s->staging_pixels) {
+        hipFree(s->d_rgb);
+        hipFree(s->d_rgba);
+        s->d_rgb = nullptr;
+        s->d_rgba = nullptr;
+        s->staging_pixels = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_rgb), pixels * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_rgba), pixels * sizeof(uint32_t)));
+        s->staging_pixels = pixels;
+    }
+    const int rc = launch(s, y0, y1 - y0, 1, 1, seed, rgb_linear_out ? s->d_rgb : nullptr,
+                          rgba8_out ? s->d_rgba : nullptr, s->stream);
+    if (rc != RTMI_OK) return rc;
+    if (rgb_linear_out) {
+        HIP_TRY(hipMemcpyAsync(rgb_linear_out, s->d_rgb, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    }
+    if (rgba8_out) {
+        HIP_TRY(hipMemcpyAsync(rgba8_out, s->d_rgba, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_get_stats(rtmi_scene* s, rtmi_stats* out, int reset) {
+    if (!s || !out) {
+        set_error("rtmi_scene_get_stats: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    std::lock_guard<std::mutex> lock(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long v[4];
+    HIP_TRY(hipMemcpy(v, s->d_stats, sizeof(v), hipMemcpyDeviceToHost));
+    out->samples = v[0];
+    out->segments = v[1];
+    out->sphere_tests = v[2];
+    out->node_tests = v[3];
+    if (reset) HIP_TRY(hipMemset(s->d_stats, 0, sizeof(v)));
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_get_accel(const rtmi_scene* s, uint32_t* accel_out) {
+    if (!s || !accel_out) {
+        set_error("rtmi_scene_get_accel: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    *accel_out = s->accel;
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_get_bvh(const rtmi_scene* s, rtmi_bvh_node* nodes_out, uint32_t* n_nodes,
+                                  uint32_t* slots_out, uint32_t* n_slots, float* pad_classes_out,
+                                  uint32_t* n_classes, float* pad_eps, float* pad_floor) {
+    if (!s) {
+        set_error("rtmi_scene_get_bvh: null scene");
+        return RTMI_ERR_BAD_ARG;
+    }
+    if (s->accel != RTMI_ACCEL_BVH) {
+        set_error("rtmi_scene_get_bvh: scene has no BVH");
+        return RTMI_ERR_UNSUPPORTED;
+    }
+    if (n_nodes) *n_nodes = (uint32_t)s->bvh.nodes.size();
+    if (n_slots) *n_slots = (uint32_t)s->bvh.slot_object.size();
+    if (n_classes) *n_classes = s->bvh.n_pad_classes;
+    if (pad_eps) *pad_eps = s->bvh.pad_eps;
+    if (pad_floor) *pad_floor = s->bvh.pad_floor;
+    if (nodes_out) std::memcpy(nodes_out, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(rtmi_bvh_node));
+    if (slots_out) std::memcpy(slots_out, s->bvh.slot_object.data(), s->bvh.slot_object.size() * sizeof(uint32_t));
+    if (pad_classes_out) std::memcpy(pad_classes_out, s->bvh.pad_classes, s->bvh.n_pad_classes * 8 * sizeof(float));
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_last_kernel_ms(rtmi_scene* s, float* ms_out) {
+    if (!s || !ms_out) {
+        set_error("rtmi_scene_last_kernel_ms: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!s->ev_valid) {
+        set_error("rtmi_scene_last_kernel_ms: no launch yet");
+        return RTMI_ERR_BAD_ARG;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    HIP_TRY(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
+    return RTMI_OK;
+}

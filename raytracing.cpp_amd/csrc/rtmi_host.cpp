@@ -1,0 +1,509 @@
+// rtmi_host.cpp -- host side of librtmi: camera derivation, scene generator, BVH builder, error text.
+//
+// Everything here runs once per scene on the CPU; the per-pixel hot path is in rtmi_device.hip.
+// Compiled with -ffp-contract=off: the camera constants feed every ray and must come out bit-identical to
+// the reference's baseline-x86-64 build (reference src/ray.tracer.core.cc:158-216).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <random>
+
+#include "rtmi_internal.h"
+
+namespace rtmi {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+namespace {
+
+struct Vec3 {
+    float x, y, z;
+};
+inline Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 operator-(Vec3 a) { return {-a.x, -a.y, -a.z}; }
+inline Vec3 operator*(Vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline Vec3 operator*(float s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline Vec3 operator*(Vec3 a, Vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline Vec3 operator/(Vec3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+// glm::dot / normalize / cross / radians as published by glm (pinned by reference CMakeLists.txt:55)
+inline float dot(Vec3 a, Vec3 b) {
+    const Vec3 t = a * b;
+    return t.x + t.y + t.z;
+}
+inline Vec3 normalize(Vec3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
+inline Vec3 cross(Vec3 x, Vec3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+inline float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
+inline Vec3 load3(const float* p) { return {p[0], p[1], p[2]}; }
+inline void store3(float* p, Vec3 v) {
+    p[0] = v.x;
+    p[1] = v.y;
+    p[2] = v.z;
+}
+
+// RandomNumberGenerator (reference src/random.number.gen.hpp:7-48) with an explicit seed instead of
+// std::random_device; same engine and distribution types.
+class HostRng {
+public:
+    explicit HostRng(uint32_t seed) : _randgen{seed} {}
+    double random_double() { return _randdist(_randgen); }
+    double random_double(double r_min, double r_max) { return r_min + (r_max - r_min) * random_double(); }
+    Vec3 random_vector(double rmin, double rmax) {
+        // braces in the reference: x, y, z are drawn left to right and narrowed to float
+        const float x = static_cast<float>(random_double(rmin, rmax));
+        const float y = static_cast<float>(random_double(rmin, rmax));
+        const float z = static_cast<float>(random_double(rmin, rmax));
+        return {x, y, z};
+    }
+
+private:
+    std::mt19937 _randgen;
+    std::uniform_real_distribution<> _randdist{0.0, 1.0};
+};
+
+} // namespace
+} // namespace rtmi
+
+using namespace rtmi;
+
+extern "C" const char* rtmi_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* rtmi_version(void) { return "rtmi 0.1 (gfx950)"; }
+
+// RayTracingCore::default_setup camera block, reference core.cc:171-216.
+extern "C" int rtmi_camera_setup(const rtmi_camera_params* cp, rtmi_camera* out) {
+    if (!cp || !out) {
+        set_error("rtmi_camera_setup: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    const uint32_t image_height = static_cast<uint32_t>(static_cast<float>(cp->image_width) / cp->aspect_ratio);
+
+    const float theta = radians(cp->vertical_fov);
+    const float h = std::tan(theta * 0.5f);
+    const float viewport_height = 2.0f * h * cp->focus_distance;
+    const float viewport_width =
+        viewport_height * (static_cast<float>(cp->image_width) / static_cast<float>(image_height));
+
+    // make_camera_frame, core.cc:158-169
+    const Vec3 lookfrom = load3(cp->lookfrom), lookat = load3(cp->lookat), world_up = load3(cp->world_up);
+    const Vec3 W = normalize(lookfrom - lookat);
+    const Vec3 U = normalize(cross(world_up, W));
+    const Vec3 V = cross(W, U);
+
+    const Vec3 viewport_u = U * viewport_width;
+    const Vec3 viewport_v = -V * viewport_height;
+    const Vec3 pixel_delta_u = viewport_u / static_cast<float>(cp->image_width);
+    const Vec3 pixel_delta_v = viewport_v / static_cast<float>(image_height);
+    const Vec3 viewport_upper_left = lookfrom - cp->focus_distance * W - viewport_u * 0.5f - viewport_v * 0.5f;
+    const Vec3 pixel00_loc = viewport_upper_left + 0.5f * (pixel_delta_u + pixel_delta_v);
+    const float defocus_radius = cp->focus_distance * std::tan(radians(cp->defocus_angle * 0.5f));
+
+    out->img_width = cp->image_width;
+    out->img_height = image_height;
+    out->defocus_angle = cp->defocus_angle;
+    out->viewport_height = viewport_height;
+    out->viewport_width = viewport_width;
+    out->samples_per_pixel = cp->samples_per_pixel;
+    out->maxdepth = cp->max_depth;
+    out->pixels_sample_scale = 1.0f / static_cast<float>(cp->samples_per_pixel);
+    store3(out->pixel_delta_u, pixel_delta_u);
+    store3(out->pixel_delta_v, pixel_delta_v);
+    store3(out->pixel00, pixel00_loc);
+    store3(out->cam_center, lookfrom);
+    store3(out->defocus_disk_u, U * defocus_radius);
+    store3(out->defocus_disk_v, V * defocus_radius);
+    return RTMI_OK;
+}
+
+// make_world_spheres, reference core.cc:99-149.
+extern "C" int rtmi_make_world_spheres(const rtmi_world_def* def, const rtmi_object* fixed_objects,
+                                       const rtmi_material* fixed_materials, uint32_t n_fixed, uint32_t mt_seed,
+                                       rtmi_object* objects_out, rtmi_material* materials_out, uint32_t capacity,
+                                       uint32_t* n_out) {
+    if (!def || !objects_out || !materials_out || !n_out || (n_fixed && (!fixed_objects || !fixed_materials))) {
+        set_error("rtmi_make_world_spheres: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    uint32_t n = 0;
+    auto push = [&](const rtmi_object& o, const rtmi_material& m) -> bool {
+        if (n >= capacity) return false;
+        objects_out[n] = o;
+        objects_out[n].material = n; // MaterialCollection::add returns the insertion index (material.defs.hpp:96-100)
+        materials_out[n] = m;
+        ++n;
+        return true;
+    };
+    auto lambertian = [](Vec3 albedo) {
+        rtmi_material m{};
+        m.kind = 0;
+        store3(m.p, albedo);
+        return m;
+    };
+    auto metallic = [](Vec3 albedo, float fuzziness) {
+        rtmi_material m{};
+        m.kind = 1;
+        store3(m.p, albedo);
+        m.p[3] = std::min(1.0f, fuzziness); // Material::make_metallic, material.defs.hpp:73
+        return m;
+    };
+    auto dielectric = [](float ri) {
+        rtmi_material m{};
+        m.kind = 2;
+        m.p[0] = ri;
+        return m;
+    };
+
+    for (uint32_t i = 0; i < n_fixed; ++i) { // core.cc:104-122
+        rtmi_object o = fixed_objects[i];
+        o.kind = 0;
+        rtmi_material m = fixed_materials[i];
+        if (m.kind == 1) m = metallic(load3(m.p), m.p[3]);
+        if (m.kind > 2) {
+            set_error("rtmi_make_world_spheres: unknown material kind");
+            return RTMI_ERR_BAD_ARG;
+        }
+        if (!push(o, m)) {
+            set_error("rtmi_make_world_spheres: capacity too small");
+            return RTMI_ERR_BAD_ARG;
+        }
+    }
+
+    HostRng rand_gen{mt_seed}; // core.cc:124
+    for (int32_t a = def->a_min; a < def->a_max; ++a) {
+        for (int32_t b = def->b_min; b < def->b_max; ++b) {
+            const float choose_mat = static_cast<float>(rand_gen.random_double());
+            // core.cc:128: `a + 0.9f * rd()` and `b + 0.9 * rd()` are double expressions narrowed by the braces
+            const float cx = static_cast<float>(a + 0.9f * rand_gen.random_double());
+            const float cy = 0.2f;
+            const float cz = static_cast<float>(b + 0.9 * rand_gen.random_double());
+            // core.cc:130: glm's vec3::length() is the component count, so the test reads `3 > treshold`
+            // (bug-compatible: no grid sphere is ever skipped for tresholds below 3).
+            if (3.0f > def->center_dist_treshold) {
+                rtmi_material m{};
+                if (choose_mat < def->diffuse_material_treshold) {
+                    const Vec3 c1 = rand_gen.random_vector(0.0f, 1.0f);
+                    const Vec3 c2 = rand_gen.random_vector(0.0f, 1.0f);
+                    m = lambertian(c1 * c2);
+                } else if (choose_mat < def->metal_material_treshold) {
+                    // core.cc:137-138: argument evaluation order of make_metallic(random_vector, random_double) is
+                    // unspecified by C++; g++/x86-64 (the reference's toolchain) evaluates right to left.
+                    const float fuzz = static_cast<float>(rand_gen.random_double(0.0f, 0.5f));
+                    const Vec3 albedo = rand_gen.random_vector(0.5f, 1.0f);
+                    m = metallic(albedo, fuzz);
+                } else {
+                    m = dielectric(static_cast<float>(rand_gen.random_double(1.2f, 1.6f)));
+                }
+                rtmi_object o{};
+                o.kind = 0;
+                o.center[0] = cx;
+                o.center[1] = cy;
+                o.center[2] = cz;
+                o.radius = 0.2f;
+                if (!push(o, m)) {
+                    set_error("rtmi_make_world_spheres: capacity too small");
+                    return RTMI_ERR_BAD_ARG;
+                }
+            }
+        }
+    }
+    *n_out = n;
+    return RTMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BVH builder (build-side extension; the reference scans linearly, object.defs.cc:68-81).
+//
+// Binary tree, each node carrying both children's boxes in centre/half-extent form so one 64-byte LDS record
+// feeds two slab tests.  Boxes are rounded outward; the kernel adds a per-ray pad (pad_classes) that covers
+// the fp32 error of the reference's sphere discriminant, so that every sphere the linear scan would accept
+// is reached by the walk (DESIGN.md "Exactness of the BVH").
+// ---------------------------------------------------------------------------------------------------------
+namespace rtmi {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int i = 0; i < 3; ++i) {
+            lo[i] = std::numeric_limits<float>::infinity();
+            hi[i] = -std::numeric_limits<float>::infinity();
+        }
+    }
+    void grow(const Box& b) {
+        for (int i = 0; i < 3; ++i) {
+            lo[i] = std::min(lo[i], b.lo[i]);
+            hi[i] = std::max(hi[i], b.hi[i]);
+        }
+    }
+    float half_area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim {
+    Box box;
+    float c[3];
+    uint32_t object;
+};
+
+inline float down(float v) { return std::nextafter(v, -std::numeric_limits<float>::infinity()); }
+inline float up(float v) { return std::nextafter(v, std::numeric_limits<float>::infinity()); }
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<rtmi_bvh_node> nodes;
+    std::vector<uint32_t> slots;
+    uint32_t leaf_size;
+    uint32_t depth = 0;
+
+    static void set_child(rtmi_bvh_node& nd, int k, const Box& b, uint32_t ref) {
+        for (int i = 0; i < 3; ++i) {
+            const float c = 0.5f * b.lo[i] + 0.5f * b.hi[i];
+            // half extent rounded up so [c-h, c+h] contains [lo, hi] despite the rounding of c
+            const float h = up(std::max(b.hi[i] - c, c - b.lo[i]));
+            nd.ctr[k][i] = c;
+            nd.half[k][i] = h;
+        }
+        nd.child[k] = ref;
+    }
+
+    // returns the reference (leaf or node index) of the subtree over prims[begin, end) and its box
+    uint32_t build(uint32_t begin, uint32_t end, uint32_t level, Box& box_out) {
+        Box box;
+        box.reset();
+        Box cbox;
+        cbox.reset();
+        for (uint32_t i = begin; i < end; ++i) {
+            box.grow(prims[i].box);
+            for (int a = 0; a < 3; ++a) {
+                cbox.lo[a] = std::min(cbox.lo[a], prims[i].c[a]);
+                cbox.hi[a] = std::max(cbox.hi[a], prims[i].c[a]);
+            }
+        }
+        box_out = box;
+        const uint32_t n = end - begin;
+        if (n <= leaf_size) {
+            const uint32_t first = static_cast<uint32_t>(slots.size());
+            for (uint32_t i = begin; i < end; ++i) slots.push_back(prims[i].object);
+            return make_leaf_ref(first, n);
+        }
+        depth = std::max(depth, level + 1);
+
+        // split: full-sweep SAH on the three axes for small ranges / shallow levels, median split otherwise
+        uint32_t mid = begin + n / 2;
+        int axis = 0;
+        {
+            float ext = -1.0f;
+            for (int a = 0; a < 3; ++a) {
+                const float e = cbox.hi[a] - cbox.lo[a];
+                if (e > ext) {
+                    ext = e;
+                    axis = a;
+                }
+            }
+        }
+        bool done = false;
+        if (level < 24 && n <= 4096) {
+            float best_cost = std::numeric_limits<float>::infinity();
+            int best_axis = -1;
+            uint32_t best_split = 0;
+            std::vector<float> right_area(n);
+            for (int a = 0; a < 3; ++a) {
+                std::sort(prims.begin() + begin, prims.begin() + end, [a](const Prim& p, const Prim& q) {
+                    return p.c[a] < q.c[a] || (p.c[a] == q.c[a] && p.object < q.object);
+                });
+                Box acc;
+                acc.reset();
+                for (uint32_t i = n; i-- > 1;) {
+                    acc.grow(prims[begin + i].box);
+                    right_area[i] = acc.half_area();
+                }
+                acc.reset();
+                for (uint32_t i = 1; i < n; ++i) {
+                    acc.grow(prims[begin + i - 1].box);
+                    const float cost = acc.half_area() * static_cast<float>(i) + right_area[i] * static_cast<float>(n - i);
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = a;
+                        best_split = i;
+                    }
+                }
+            }
+            if (best_axis >= 0) {
+                const int a = best_axis;
+                std::sort(prims.begin() + begin, prims.begin() + end, [a](const Prim& p, const Prim& q) {
+                    return p.c[a] < q.c[a] || (p.c[a] == q.c[a] && p.object < q.object);
+                });
+                mid = begin + best_split;
+                done = true;
+            }
+        } else if (level < 24) {
+            // binned SAH (32 bins) on the widest centroid axis
+            constexpr int kBins = 32;
+            const float lo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
+            if (ext > 0.0f) {
+                Box bins[kBins];
+                uint32_t cnt[kBins] = {};
+                for (auto& b : bins) b.reset();
+                auto bin_of = [&](const Prim& p) {
+                    int k = static_cast<int>(kBins * ((p.c[axis] - lo) / ext));
+                    return std::min(std::max(k, 0), kBins - 1);
+                };
+                for (uint32_t i = begin; i < end; ++i) {
+                    const int k = bin_of(prims[i]);
+                    bins[k].grow(prims[i].box);
+                    cnt[k]++;
+                }
+                float ra[kBins];
+                uint32_t rc[kBins];
+                Box acc;
+                acc.reset();
+                uint32_t c = 0;
+                for (int k = kBins - 1; k > 0; --k) {
+                    acc.grow(bins[k]);
+                    c += cnt[k];
+                    ra[k] = acc.half_area();
+                    rc[k] = c;
+                }
+                acc.reset();
+                c = 0;
+                float best_cost = std::numeric_limits<float>::infinity();
+                int best_k = -1;
+                for (int k = 1; k < kBins; ++k) {
+                    acc.grow(bins[k - 1]);
+                    c += cnt[k - 1];
+                    if (c == 0 || rc[k] == 0) continue;
+                    const float cost = acc.half_area() * static_cast<float>(c) + ra[k] * static_cast<float>(rc[k]);
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_k = k;
+                    }
+                }
+                if (best_k > 0) {
+                    auto it = std::partition(prims.begin() + begin, prims.begin() + end,
+                                             [&](const Prim& p) { return bin_of(p) < best_k; });
+                    mid = static_cast<uint32_t>(it - prims.begin());
+                    done = mid > begin && mid < end;
+                }
+            }
+        }
+        if (!done) {
+            std::nth_element(prims.begin() + begin, prims.begin() + begin + n / 2, prims.begin() + end,
+                             [axis](const Prim& p, const Prim& q) {
+                                 return p.c[axis] < q.c[axis] || (p.c[axis] == q.c[axis] && p.object < q.object);
+                             });
+            mid = begin + n / 2;
+        }
+
+        const uint32_t me = static_cast<uint32_t>(nodes.size());
+        nodes.emplace_back();
+        Box lb, rb;
+        const uint32_t l = build(begin, mid, level + 1, lb);
+        const uint32_t r = build(mid, end, level + 1, rb);
+        rtmi_bvh_node nd{};
+        set_child(nd, 0, lb, l);
+        set_child(nd, 1, rb, r);
+        nodes[me] = nd;
+        return me;
+    }
+};
+
+} // namespace
+
+void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& out) {
+    Builder b;
+    b.leaf_size = std::min(std::max(leaf_size, 1u), kMaxLeafSize);
+    b.prims.resize(n);
+    float maxabs = 0.0f;
+    float rmin_all = std::numeric_limits<float>::infinity(), rmax_all = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) {
+        Prim& p = b.prims[i];
+        const float r = std::fabs(objects[i].radius);
+        for (int a = 0; a < 3; ++a) {
+            p.c[a] = objects[i].center[a];
+            p.box.lo[a] = down(objects[i].center[a] - r);
+            p.box.hi[a] = up(objects[i].center[a] + r);
+            maxabs = std::max(maxabs, std::max(std::fabs(p.box.lo[a]), std::fabs(p.box.hi[a])));
+        }
+        p.object = i;
+        rmin_all = std::min(rmin_all, r);
+        rmax_all = std::max(rmax_all, r);
+    }
+    b.nodes.reserve(n);
+    b.slots.reserve(n);
+    Box root_box;
+    out.root_ref = n ? b.build(0, n, 0, root_box) : make_leaf_ref(0, 0);
+    out.nodes = std::move(b.nodes);
+    out.slot_object = std::move(b.slots);
+    out.depth = b.depth;
+
+    // Per-ray pad: a sphere of radius R seen from distance L is accepted by the fp32 discriminant of
+    // object.defs.cc:43-50 only if the ray passes within sqrt(R^2 + k*u*L^2) of its centre (u = 2^-24, k <= 15),
+    // i.e. within R + k*u*L^2/(2R).  Spheres are grouped into radius classes; the kernel evaluates
+    // pad = max_c(pad_eps * far2(origin, centre_box_c) / (2 rmin_c)) once per ray segment.
+    out.pad_eps = 32.0f * 5.9604645e-8f;
+    out.pad_floor = std::max(8.0f * 5.9604645e-8f * maxabs, 1e-6f);
+    out.n_pad_classes = 0;
+    if (n) {
+        const float l0 = std::log2(std::max(rmin_all, 1e-30f));
+        const float l1 = std::log2(std::max(rmax_all, 1e-30f));
+        const float step = (l1 - l0) / static_cast<float>(kMaxPadClasses);
+        Box cb[kMaxPadClasses];
+        float rmin[kMaxPadClasses];
+        bool used[kMaxPadClasses] = {};
+        for (uint32_t k = 0; k < kMaxPadClasses; ++k) {
+            cb[k].reset();
+            rmin[k] = std::numeric_limits<float>::infinity();
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            const float r = std::max(std::fabs(objects[i].radius), 1e-30f);
+            uint32_t k = 0;
+            if (step > 0.0f) {
+                k = static_cast<uint32_t>(std::min(std::max((std::log2(r) - l0) / step, 0.0f),
+                                                   static_cast<float>(kMaxPadClasses - 1)));
+            }
+            used[k] = true;
+            rmin[k] = std::min(rmin[k], r);
+            for (int a = 0; a < 3; ++a) {
+                cb[k].lo[a] = std::min(cb[k].lo[a], objects[i].center[a]);
+                cb[k].hi[a] = std::max(cb[k].hi[a], objects[i].center[a]);
+            }
+        }
+        for (uint32_t k = 0; k < kMaxPadClasses; ++k) {
+            if (!used[k]) continue;
+            float* pc = out.pad_classes[out.n_pad_classes++];
+            for (int a = 0; a < 3; ++a) {
+                pc[a] = cb[k].lo[a];
+                pc[3 + a] = cb[k].hi[a];
+            }
+            pc[6] = 1.0f / (2.0f * rmin[k]);
+            pc[7] = 0.0f;
+        }
+    }
+}
+
+} // namespace rtmi
+
+extern "C" int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size,
+                              rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref,
+                              uint32_t* depth, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,
+                              float* pad_floor) {
+    if (n_objects && !objects) {
+        set_error("rtmi_bvh_build: null objects");
+        return RTMI_ERR_BAD_ARG;
+    }
+    Bvh bvh;
+    build_bvh(objects, n_objects, leaf_size ? leaf_size : 2u, bvh);
+    if (n_nodes) *n_nodes = static_cast<uint32_t>(bvh.nodes.size());
+    if (root_ref) *root_ref = bvh.root_ref;
+    if (depth) *depth = bvh.depth;
+    if (n_classes) *n_classes = bvh.n_pad_classes;
+    if (pad_eps) *pad_eps = bvh.pad_eps;
+    if (pad_floor) *pad_floor = bvh.pad_floor;
+    if (nodes_out && !bvh.nodes.empty()) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtmi_bvh_node));
+    if (slots_out && n_objects) std::memcpy(slots_out, bvh.slot_object.data(), n_objects * sizeof(uint32_t));
+    if (pad_classes_out) std::memcpy(pad_classes_out, bvh.pad_classes, sizeof(bvh.pad_classes));
+    return RTMI_OK;
+}

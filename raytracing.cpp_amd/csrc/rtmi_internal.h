@@ -1,0 +1,39 @@
+// rtmi_internal.h -- shared between the host side (rtmi_host.cpp) and the HIP side (rtmi_device.hip).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rtmi.h"
+
+namespace rtmi {
+
+static_assert(sizeof(rtmi_object) == 24, "HittableObject layout (reference object.defs.hpp:30-57) is 24 bytes");
+static_assert(sizeof(rtmi_material) == 20, "Material layout (reference material.defs.hpp:49-55) is 20 bytes");
+static_assert(sizeof(rtmi_bvh_node) == 64, "BVH node is one 64-byte LDS record");
+static_assert(sizeof(rtmi_camera) == 100, "14 POD fields of RayTracingCore (reference core.hpp:19-32)");
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kMaxPadClasses = 4;
+constexpr uint32_t kMaxLeafSize = 4;
+
+inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return kLeafBit | (count << 24) | first; }
+
+// Host-built acceleration structure.  Slots are the spheres in leaf order; slot_object[i] is the index of the
+// object (in insertion order, i.e. the order HittableObject_Collection::add_object was called) stored at slot i.
+struct Bvh {
+    std::vector<rtmi_bvh_node> nodes; // empty when the whole scene is one leaf
+    std::vector<uint32_t> slot_object;
+    uint32_t root_ref = 0;
+    uint32_t depth = 0; // number of internal levels on the longest root-to-leaf path (== max stack entries)
+    float pad_classes[kMaxPadClasses][8] = {};
+    uint32_t n_pad_classes = 0;
+    float pad_eps = 0.0f;
+    float pad_floor = 0.0f;
+};
+
+void set_error(const std::string& msg);
+void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& out);
+
+} // namespace rtmi
