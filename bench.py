@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the path-tracing hot loop on MI355X.
+
+A step = one pass of the hot path over one frame of the S-RTOW workload: the reference's RTOW
+"final scene" generator (488 spheres, seed 12345), 1920x1080, 512 spp, 50 bounces -- the configuration
+BASELINE.json's metric is quoted on.  At N = 1 one GPU renders the whole frame; at N > 1 the image plane is
+sharded by interleaved 8-row blocks, every rank renders its blocks and rank 0 gathers the framebuffer slices with
+one RCCL gather (strong scaling: the frame is fixed).  Scene and BVH are resident in HBM before the timed region;
+the frame stays in HBM (no PCIe in the timed region).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      algorithmic flops per launch (SURVEY 8d formula, counters from the CPU oracle's instrumented walk
+                of the same BVH) / mean kernel duration from HIP events on the launch stream
+  cpu_baseline  the oracle (a port of the reference's CPU path, reference-shaped job system) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _ROOT)
+
+# S-RTOW workload (metric config of BASELINE.json)
+WIDTH, SPP, DEPTH = 1920, 512, 50
+SCENE_SEED, RENDER_SEED = 12345, 2025
+BLOCK_ROWS = 8
+# non-FMA fp32 VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md; its 157.3 TFLOP/s
+# vector peak counts an FMA as 2 flops, which the no-contraction parity bar rules out for the reference arithmetic)
+VALU_PEAK_TFLOPS = 78.6
+
+
+def flops_per_sample(ctr):
+    """S * (T_sphere * 23 + T_node * 30 + 70), all per-sample means."""
+    n = float(ctr["samples"])
+    seg = ctr["segments"] / n
+    return seg * 70.0 + ctr["sphere_tests"] / n * 23.0 + ctr["node_tests"] / n * 30.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--accel", choices=("bvh", "brute"), default="bvh")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline renders every n-th pixel in x and y")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import rtmi_loader
+    pkg = rtmi_loader.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cp = pkg.camera_params(image_width=args.width, samples_per_pixel=args.spp, max_depth=args.depth)
+    cam = pkg.camera_setup(cp)
+    objs, mats = pkg.make_world_spheres(SCENE_SEED)
+    W, H = cam.img_width, cam.img_height
+    accel = pkg.ACCEL_BVH if args.accel == "bvh" else pkg.ACCEL_BRUTE
+    scene = pkg.Scene(cam, objs, mats, accel=accel, device=local_rank)
+
+    plan = pkg.RowShardPlan(H, BLOCK_ROWS, world)
+    y_first, n_blocks, rows = plan.shard(rank)
+    rgb = torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev)
+    rgba = torch.zeros((plan.max_rows, W, 1), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    kernel_ms = []
+
+    def step(record=False):
+        if n_blocks:
+            scene.render_row_blocks_device(y_first, BLOCK_ROWS, world, n_blocks, RENDER_SEED, rgb.data_ptr(),
+                                           rgba.data_ptr(), stream)
+        frame = pkg.gather_frame(rgb, plan, rank)
+        frame8 = pkg.gather_frame(rgba, plan, rank)
+        return frame, frame8
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame, frame8 = step()
+        # per-launch duration from the HIP events the library records on the launch stream (blocks on that launch;
+        # the next step cannot start earlier anyway because it reuses the same output buffers)
+        if n_blocks:
+            kernel_ms.append(scene.last_kernel_ms())
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kmean = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=dev)
+    kmax = kmean.clone()
+    if world > 1:
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+
+    if rank == 0:
+        samples = W * H * args.spp
+        ms_per_step = elapsed / args.steps * 1e3
+        value = samples / (elapsed / args.steps) / 1e6
+        out = {
+            "metric": "Msamples/sec (W*H*spp/s), RTOW final scene",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S-RTOW(seed {SCENE_SEED}) {len(objs)} spheres, {W}x{H}, {args.spp} spp, "
+                                   f"{args.depth} bounces, accel={args.accel}",
+                       "sharding": f"interleaved {BLOCK_ROWS}-row blocks x{world}, 1 gather to rank 0",
+                       "resident": "scene+BVH in HBM before the timed region; frame stays in HBM"},
+        }
+        # ---- parity spot check + algorithmic work counters from the CPU oracle (checker only) -------------
+        from oracle import binding as ob
+        ocam = ob.camera_setup(ob.camera_params(image_width=args.width, samples_per_pixel=args.spp,
+                                                max_depth=args.depth))
+        frame_h = frame.cpu().numpy()
+        rng = np.random.default_rng(1)
+        n_chk = 48
+        xs, ys = rng.integers(0, W, n_chk), rng.integers(0, H, n_chk)
+        worst = 0.0
+        nthreads = max(1, (os.cpu_count() or 1) - (2 if (os.cpu_count() or 1) > 6 else 0))
+        for x, y in zip(xs, ys):
+            want, _ = ob.render_rect_counter(ocam, objs, mats, RENDER_SEED, int(x), int(y), int(x) + 1, int(y) + 1)
+            worst = max(worst, float(np.abs(frame_h[y, x] - want[0, 0]).max()))
+        out["parity_check"] = {"pixels": n_chk, "max_abs_diff_vs_oracle": worst}
+        bvh = pkg.bvh_build(objs) if args.accel == "bvh" else None
+        if bvh is not None:
+            bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
+        ctr_stride = 24
+        ctr = {"samples": 0, "segments": 0, "sphere_tests": 0, "node_tests": 0}
+        sub_spp = min(args.spp, 64)
+        ccam = ob.camera_setup(ob.camera_params(image_width=args.width, samples_per_pixel=sub_spp,
+                                                max_depth=args.depth))
+        for y in range(ctr_stride // 2, H, ctr_stride):
+            for x in range(ctr_stride // 2, W, ctr_stride * 4):
+                _, _, c = ob.render_rect_counter(ccam, objs, mats, RENDER_SEED, x, y, x + 1, y + 1, counters=True,
+                                                 bvh=bvh)
+                for k in ctr:
+                    ctr[k] += c[k]
+        fps = flops_per_sample(ctr)
+        kernel_s = float(kmax.item()) / 1e3
+        samples_per_launch = samples / world
+        achieved = samples_per_launch * fps / kernel_s / 1e12
+        traffic = None
+        tpath = os.path.join(_ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("width") == args.width and tj.get("spp") == args.spp and tj.get("n_gpus") == world:
+                    traffic = tj.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "bound": "valu", "achieved": round(achieved, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+            "kernel": "rtmi_trace_kernel<%s>" % args.accel, "kernel_ms": round(kernel_s * 1e3, 3),
+            "flops_per_sample": round(fps, 1),
+            "counters_per_sample": {k: round(ctr[k] / ctr["samples"], 3) for k in ctr if k != "samples"},
+            "counters_source": f"oracle instrumented walk, {ctr['samples']} samples on a uniform pixel subset",
+            "hbm_algorithmic_bytes_per_launch": int(len(objs) * (16 + 16 + 32) + (0 if bvh is None else len(bvh["nodes"]) * 64)
+                                                    + W * (H // world) * 16),
+            "note": "fp32 VALU-bound path (SURVEY 8d): peak = non-FMA issue rate 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
+        }
+        # ---- CPU baseline: the oracle, reference-shaped job system, on this host's cores -----------------------
+        if world == 1 and not args.no_cpu_baseline:
+            hw = os.cpu_count() or 1
+            try:
+                hw = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            threads = hw - 2 if hw > 6 else hw  # src/main.cc:608-611
+            secs, n = ob.bench_mt(ocam, objs, mats, SCENE_SEED, args.cpu_stride, threads)
+            secs1, n1 = ob.bench_mt(ocam, objs, mats, SCENE_SEED, args.cpu_stride * 6, 1)
+            out["cpu_baseline"] = {
+                "value": round(n / secs / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                "sample": f"every {args.cpu_stride}th pixel in x and y of the same frame at full spp "
+                          f"({n} samples, {secs:.1f} s); mt19937 per worker, shuffled 8x8 tiles (src/main.cc:608-633)",
+                "single_thread_value": round(n1 / secs1 / 1e6, 4), "host_cpus": hw,
+            }
+            out["gpu_over_cpu"] = round(value / (n / secs / 1e6), 1)
+        print(json.dumps(out), flush=True)
+
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

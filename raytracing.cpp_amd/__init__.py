@@ -319,3 +319,41 @@ def deinterleave_rows(height, block_rows, world_size):
         r, k = b % world_size, b // world_size
         idx[y] = r * max_rows + k * block_rows + (y - b * block_rows)
     return idx, max_rows
+
+
+# ---------------------------------------------------------------------------------------------------------
+# multi-GPU plumbing: interleaved row-block sharding + one gather of the per-rank framebuffer slices
+# (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests)
+# ---------------------------------------------------------------------------------------------------------
+class RowShardPlan:
+    """Row-block sharding of an image of `height` rows over `world_size` ranks.
+
+    Block b (block_rows rows) belongs to rank b % world_size, so that the expensive lower rows and the cheap sky
+    rows are spread evenly.  Every rank renders its blocks into a dense slice padded to `max_rows` rows; rank 0
+    gathers the slices and `index` maps the rank-major gathered rows back to scanline order."""
+
+    def __init__(self, height, block_rows, world_size):
+        self.height, self.block_rows, self.world_size = height, block_rows, world_size
+        self.shards = row_block_shards(height, block_rows, world_size)
+        self.index, self.max_rows = deinterleave_rows(height, block_rows, world_size)
+
+    def shard(self, rank):
+        """(y_first, n_blocks, rows) of `rank`; block stride is world_size."""
+        return self.shards[rank]
+
+
+def gather_frame(local_slice, plan, rank, dst=0, group=None):
+    """Gathers the per-rank slices ([max_rows, W, C] tensors) to `dst` and returns the de-interleaved
+    [height, W, C] frame there (None elsewhere).  One collective, no data-path exchange otherwise."""
+    import torch
+    import torch.distributed as dist
+    if plan.world_size == 1:
+        return local_slice[:plan.height]
+    if rank == dst:
+        parts = [torch.empty_like(local_slice) for _ in range(plan.world_size)]
+        dist.gather(local_slice, parts, dst=dst, group=group)
+        stacked = torch.cat(parts, dim=0)
+        idx = torch.as_tensor(plan.index, device=stacked.device)
+        return stacked.index_select(0, idx)
+    dist.gather(local_slice, None, dst=dst, group=group)
+    return None

@@ -554,7 +554,7 @@ struct rtmi_scene {
     // launch geometry
     uint32_t block = 512, grid = 0, lds_bytes = 0, stack_depth = 0;
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
-    uint32_t wait_thresh = 24;
+    uint32_t wait_thresh = 64;
     hipStream_t stream = nullptr; // private stream of the blocking entry point
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;

@@ -1,0 +1,170 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol of include/rtmi.h, the
+host logic (camera derivation, scene generator, BVH builder, row sharding) matches the oracle, and the compute entry
+points fail loudly without a GPU.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = open(os.path.join(ROOT, "include", "rtmi.h")).read()
+    declared = set(re.findall(r"\b(rtmi_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(pkg.EXPORTS), declared ^ set(pkg.EXPORTS)
+    lib = pkg.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.rtmi_version()
+
+
+def test_struct_layouts_match_reference_records(pkg):
+    # HittableObject 24 B (object.defs.hpp:30-57), Material 20 B (material.defs.hpp:49-55),
+    # 14 PODs of RayTracingCore = 100 B (core.hpp:19-32), CameraParameters 60 B (camera.parameters.hpp:6-17)
+    assert pkg.OBJECT_DTYPE.itemsize == 24 and pkg.MATERIAL_DTYPE.itemsize == 20
+    assert C.sizeof(pkg.Camera) == 100 and C.sizeof(pkg.CameraParams) == 60
+    assert pkg.BVH_NODE_DTYPE.itemsize == 64
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), dict(image_width=400), dict(image_width=1920, samples_per_pixel=512),
+    dict(aspect_ratio=1.7, samples_per_pixel=8, max_depth=8),  # data/config/world.config.json:3-8
+    dict(aspect_ratio=1.0, image_width=800, vertical_fov=40.0, defocus_angle=0.0, lookfrom=(0, 0, 18)),
+    dict(image_width=801, vertical_fov=90.0, defocus_angle=10.0, focus_distance=3.4, lookfrom=(-2, 2, 1),
+         lookat=(0, 0, -1)),  # WorldDefinition defaults, core.cc:68-79
+])
+def test_camera_setup_matches_oracle_bit_for_bit(pkg, ob, kw):
+    a = pkg.camera_setup(pkg.camera_params(**kw))
+    b = ob.camera_setup(ob.camera_params(**kw))
+    assert bytes(a) == bytes(b)
+
+
+def test_world_generator_matches_oracle_bit_for_bit(pkg, ob):
+    """Product: std::mt19937 + std::uniform_real_distribution<double>, as the reference; oracle: plain-C restatement."""
+    for seed, kw in ((12345, {}), (1, {}), (777, dict(a_min=-3, a_max=5, b_min=0, b_max=2, diffuse=0.5, metal=0.7))):
+        o1, m1 = pkg.make_world_spheres(seed, pkg.world_def(**kw))
+        o2, m2 = ob.make_world_spheres(seed, ob.world_def(**kw))
+        assert o1.tobytes() == o2.tobytes() and m1.tobytes() == m2.tobytes()
+    o, _ = pkg.make_world_spheres(12345)
+    assert len(o) == 488
+
+
+def test_compute_entry_points_fail_loudly_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    cam = pkg.camera_setup(pkg.camera_params(image_width=64))
+    objs, mats = pkg.make_world_spheres(1)
+    with pytest.raises(pkg.RtmiError) as e:
+        pkg.Scene(cam, objs, mats)
+    assert e.value.code == pkg.RTMI_ERR_HIP
+
+
+def test_scene_create_argument_errors(pkg):
+    """Bad arguments are reported as RTMI_ERR_BAD_ARG with a message, never by aborting (main.cc's worker setup
+    failures just return; material.defs.hpp:104 asserts on bad handles)."""
+    cam = pkg.camera_setup(pkg.camera_params(image_width=64))
+    objs, mats = pkg.make_world_spheres(1)
+    bad = objs.copy()
+    bad["material"][3] = len(mats)
+    for o, m, c in ((bad, mats, cam), (objs, mats[:10], cam)):
+        with pytest.raises(pkg.RtmiError) as e:
+            pkg.Scene(c, o, m)
+        assert e.value.code == pkg.RTMI_ERR_BAD_ARG and "material" in str(e.value)
+    badk = objs.copy()
+    badk["kind"][0] = 7
+    with pytest.raises(pkg.RtmiError) as e:
+        pkg.Scene(cam, badk, mats)
+    assert e.value.code == pkg.RTMI_ERR_BAD_ARG
+    assert pkg.lib().rtmi_scene_create(None, None, 0, None, 0, None, None) == pkg.RTMI_ERR_BAD_ARG
+    assert pkg.lib().rtmi_render_rows(None, 0, 1, 0, None, None) == pkg.RTMI_ERR_BAD_ARG
+    pkg.lib().rtmi_scene_destroy(None)  # no-op
+
+
+def _check_bvh(pkg, objs, leaf):
+    b = pkg.bvh_build(objs, leaf)
+    n = len(objs)
+    assert sorted(b["slots"].tolist()) == list(range(n))  # every object in exactly one leaf slot
+    nodes = b["nodes"]
+    seen = np.zeros(n, bool)
+
+    def box_of(ref):
+        """returns (lo, hi) of everything below ref, checking containment on the way; also max depth"""
+        if ref & 0x80000000:
+            first, cnt = ref & 0xffffff, (ref >> 24) & 0x7f
+            assert 1 <= cnt <= max(leaf, 1) or n == 0
+            lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+            for s in range(first, first + cnt):
+                o = objs[b["slots"][s]]
+                assert not seen[b["slots"][s]]
+                seen[b["slots"][s]] = True
+                c, r = o["center"].astype(np.float64), abs(float(o["radius"]))
+                lo, hi = np.minimum(lo, c - r), np.maximum(hi, c + r)
+            return lo, hi, 0
+        nd = nodes[ref]
+        lo, hi, depth = np.full(3, np.inf), np.full(3, -np.inf), 0
+        for k in range(2):
+            clo, chi, d = box_of(int(nd["child"][k]))
+            blo = nd["ctr"][k].astype(np.float64) - nd["half"][k].astype(np.float64)
+            bhi = nd["ctr"][k].astype(np.float64) + nd["half"][k].astype(np.float64)
+            assert np.all(blo <= clo) and np.all(bhi >= chi)  # stored box contains the subtree (outward rounding)
+            lo, hi, depth = np.minimum(lo, clo), np.maximum(hi, chi), max(depth, d)
+        return lo, hi, depth + 1
+
+    if n:
+        _, _, depth = box_of(b["root_ref"])
+        assert seen.all() and depth == b["depth"]
+    assert b["pad_eps"] > 0 and b["pad_floor"] > 0 and 1 <= len(b["pad_classes"]) <= 4 or n == 0
+    return b
+
+
+def test_bvh_builder_invariants(pkg, rtow):
+    from tests.scenes import cornell_like, random_spheres, three_spheres
+    b = _check_bvh(pkg, rtow[0], 2)
+    assert b["depth"] <= 16 and len(b["nodes"]) < 488
+    for leaf in (1, 4):
+        _check_bvh(pkg, rtow[0], leaf)
+    _check_bvh(pkg, three_spheres()[0], 2)
+    _check_bvh(pkg, cornell_like()[0], 2)
+    _check_bvh(pkg, random_spheres(3000, seed=3)[0], 2)
+    one = rtow[0][:1].copy()
+    b = _check_bvh(pkg, one, 2)
+    assert len(b["nodes"]) == 0 and b["root_ref"] == 0x80000000 | (1 << 24)
+    dup = np.concatenate([rtow[0][4:5]] * 9)  # identical spheres: splits must still terminate
+    dup["material"] = 0
+    _check_bvh(pkg, dup, 2)
+
+
+@pytest.mark.parametrize("height,block,world", [(1080, 8, 1), (1080, 8, 8), (675, 8, 2), (675, 8, 4), (225, 16, 8),
+                                                (7, 8, 4), (54, 8, 3)])
+def test_row_block_sharding_covers_every_row_once(pkg, height, block, world):
+    plan = pkg.RowShardPlan(height, block, world)
+    owner = np.full(height, -1)
+    for r in range(world):
+        y_first, n_blocks, rows = plan.shard(r)
+        got = 0
+        for k in range(n_blocks):
+            y0 = y_first + k * world * block
+            y1 = min(height, y0 + block)
+            assert np.all(owner[y0:y1] == -1)
+            owner[y0:y1] = r
+            got += y1 - y0
+        assert got == rows <= plan.max_rows
+    assert np.all(owner >= 0)
+    # load balance of interleaving: no rank has more than one block more than another
+    rows = [s[2] for s in plan.shards]
+    assert max(rows) - min(rows) <= block
+    # de-interleave map: gathered (rank-major, padded) row -> scanline
+    stacked = np.full((world * plan.max_rows,), -1)
+    for r in range(world):
+        y_first, n_blocks, _ = plan.shard(r)
+        loc = 0
+        for k in range(n_blocks):
+            y0 = y_first + k * world * block
+            for y in range(y0, min(height, y0 + block)):
+                stacked[r * plan.max_rows + loc] = y
+                loc += 1
+    assert np.array_equal(stacked[plan.index], np.arange(height))

@@ -1,0 +1,287 @@
+"""CPU tests of the oracle itself: known-answer vectors of the generators it restates, the reference pixel values
+recorded by the survey session, the committed golden fixtures, and the edge cases of the path's unit functions."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+
+def _f3(v):
+    return (C.c_float * 3)(*v)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# generators
+# ---------------------------------------------------------------------------------------------------------------
+def test_mt19937_known_answer(ob):
+    """[rand.predef]: the 10000th consecutive invocation of a default-constructed mt19937 (seed 5489) is 4123659995."""
+    L = ob.lib()
+    r = L.orc_rng_new_mt(5489)
+    v = 0
+    for _ in range(10000):
+        v = L.orc_mt_next_u32(r)
+    L.orc_rng_free(r)
+    assert v == 4123659995
+
+
+def test_mt19937_matches_numpy_stream(ob):
+    bg = np.random.MT19937()
+    bg._legacy_seeding(12345)
+    want = bg.random_raw(2000)
+    L = ob.lib()
+    r = L.orc_rng_new_mt(12345)
+    got = [L.orc_mt_next_u32(r) for _ in range(2000)]
+    L.orc_rng_free(r)
+    assert got == [int(v) for v in want]
+
+
+def test_generate_canonical_double(ob):
+    """libstdc++ generate_canonical<double,53>(mt19937): (lo + hi * 2^32) / 2^64 with one rounding."""
+    bg = np.random.MT19937()
+    bg._legacy_seeding(99)
+    raw = bg.random_raw(200).astype(np.uint64)
+    L = ob.lib()
+    r = L.orc_rng_new_mt(99)
+    for i in range(100):
+        lo, hi = int(raw[2 * i]), int(raw[2 * i + 1])
+        want = float(np.float64(lo + hi * 2 ** 32)) / 2.0 ** 64  # python int -> float64 rounds to nearest even
+        assert L.orc_rng_double(r) == min(want, np.nextafter(1.0, 0.0))
+    L.orc_rng_free(r)
+
+
+PHILOX_KAT = [  # Random123 kat_vectors, philox4x32 10 rounds
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", PHILOX_KAT)
+def test_philox4x32_10_known_answers(ob, ctr, key, want):
+    c = np.array(ctr, np.uint32)
+    k = np.array(key, np.uint32)
+    o = np.zeros(4, np.uint32)
+    ob.lib().orc_philox4x32_10(c.ctypes.data, k.ctypes.data, o.ctypes.data)
+    assert tuple(int(v) for v in o) == want
+
+
+def test_counter_stream_definition(ob):
+    """draw k of (seed, pixel, sample) = word k&3 of Philox({k>>2, sample, pixel, 0}, seed) * 2^-32."""
+    seed, pixel, sample = 0x1234567890ABCDEF, 4321, 17
+    key = np.array([seed & 0xffffffff, seed >> 32], np.uint32)
+    for k in range(11):
+        c = np.array([k >> 2, sample, pixel, 0], np.uint32)
+        o = np.zeros(4, np.uint32)
+        ob.lib().orc_philox4x32_10(c.ctypes.data, key.ctypes.data, o.ctypes.data)
+        assert ob.lib().orc_counter_double(seed, pixel, sample, k) == int(o[k & 3]) / 2.0 ** 32
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's own outputs and the committed fixtures
+# ---------------------------------------------------------------------------------------------------------------
+def test_reference_pixels_from_survey(ob):
+    """Four RGBA8 pixels produced by the reference's own TUs (recorded in SURVEY.md 8c): the oracle's mt19937 path
+    -- scene generator, camera, 100 spp x 50 bounces, all three materials -- reproduces them bit for bit."""
+    ref = json.load(open(os.path.join(GOLDEN, "reference_pixels.json")))
+    cam = ob.camera_setup(ob.camera_params(**{k: (tuple(v) if isinstance(v, list) else v)
+                                              for k, v in ref["camera"].items()}))
+    fixed = [(tuple(c), r, (k, tuple(p))) for c, r, (k, p) in ref["fixed"]]
+    objs, mats = ob.make_world_spheres(ref["mt_seed"], ob.world_def(**ref["world_def"]), fixed)
+    assert len(objs) == 488
+    xy = [(x, y) for x, y, _ in ref["pixels"]]
+    _, rgba = ob.render_pixels_mt(cam, objs, mats, ref["mt_seed"], xy)
+    assert [hex(int(v)) for v in rgba] == [p[2] for p in ref["pixels"]]
+
+
+def test_golden_scene_and_cameras(ob, rtow):
+    g = np.load(os.path.join(GOLDEN, "rtow_scene_seed12345.npz"))
+    assert rtow[0].tobytes() == g["objects"].tobytes() and rtow[1].tobytes() == g["materials"].tobytes()
+    cams = json.load(open(os.path.join(GOLDEN, "rtow_cameras.json")))
+    for w, want in cams.items():
+        cam = ob.camera_setup(ob.camera_params(image_width=int(w)))
+        for name, _ in ob.Camera._fields_:
+            got = getattr(cam, name)
+            got = list(got) if hasattr(got, "__len__") else got
+            assert got == want[name], name
+    # H = uint32(float(W) / aspect), core.cc:174-175
+    assert [cams[w]["img_height"] for w in ("400", "1200", "1920")] == [225, 675, 1080]
+
+
+def test_golden_counter_frame(ob, rtow):
+    g = np.load(os.path.join(GOLDEN, "rtow_counter_128x72x16.npz"))
+    cp = json.loads(str(g["camera"]))
+    cam = ob.camera_setup(ob.camera_params(**cp))
+    rgb, rgba = ob.render_rect_counter(cam, *rtow, int(g["seed"]), 0, 0, cam.img_width, cam.img_height, nthreads=8)
+    assert rgb.tobytes() == g["rgb"].tobytes() and rgba.tobytes() == g["rgba"].tobytes()
+
+
+def test_golden_mt_pixels(ob, rtow):
+    g = json.load(open(os.path.join(GOLDEN, "rtow_mt_pixels.json")))
+    cam = ob.camera_setup(ob.camera_params())
+    rgb, rgba = ob.render_pixels_mt(cam, *rtow, g["mt_seed"], g["xy"])
+    assert [int(v) for v in rgba] == g["rgba"]
+    assert rgb.tolist() == g["rgb"]
+
+
+def test_counter_render_independent_of_tiling_and_threads(ob, rtow):
+    cam = ob.camera_setup(ob.camera_params(image_width=64, samples_per_pixel=4, max_depth=10))
+    full, _ = ob.render_rect_counter(cam, *rtow, 5, 0, 0, 64, 36, nthreads=1)
+    part, _ = ob.render_rect_counter(cam, *rtow, 5, 16, 9, 48, 27, nthreads=3)
+    assert np.array_equal(full[9:27, 16:48], part)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# scene generator
+# ---------------------------------------------------------------------------------------------------------------
+def test_world_generator_bug_compatible(ob):
+    objs, mats = ob.make_world_spheres(12345)
+    assert len(objs) == 4 + 22 * 22  # vec3::length() == 3 > treshold: no grid sphere is ever skipped (core.cc:130)
+    assert np.all(objs["material"] == np.arange(len(objs)))
+    assert np.all(objs["radius"][4:] == np.float32(0.2)) and np.all(objs["center"][4:, 1] == np.float32(0.2))
+    kinds = np.bincount(mats["kind"][4:], minlength=3) / (22 * 22)
+    assert abs(kinds[0] - 0.8) < 0.06 and abs(kinds[1] - 0.15) < 0.05 and abs(kinds[2] - 0.05) < 0.04
+    assert np.all(mats["p"][mats["kind"] == 1][:, 3] <= 0.5)
+    ri = mats["p"][4:][mats["kind"][4:] == 2][:, 0]
+    assert np.all((ri >= 1.2) & (ri < 1.6))
+    only_fixed, _ = ob.make_world_spheres(12345, ob.world_def(center_dist_treshold=3.0))
+    assert len(only_fixed) == 4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# unit functions: edge cases of HittableObject_Sphere::intersects / Collection::intersects
+# ---------------------------------------------------------------------------------------------------------------
+def _sphere_hit(ob, c, r, o, d, tmin=0.0001, tmax=float("inf")):
+    rec = (C.c_float * 8)()
+    ok = ob.lib().orc_sphere_intersect(_f3(c), r, _f3(o), _f3(d), tmin, tmax, rec)
+    return ok, list(rec)
+
+
+def test_sphere_intersect_edge_cases(ob):
+    # head-on hit from outside: front face, outward normal
+    ok, rec = _sphere_hit(ob, (0, 0, -5), 1.0, (0, 0, 0), (0, 0, -2))
+    assert ok and rec[6] == 2.0 and rec[7] == 1.0 and rec[3:6] == [0.0, 0.0, 1.0]  # t is in units of |d| = 2
+    # origin inside: first root is negative, second root taken, normal flipped inward
+    ok, rec = _sphere_hit(ob, (0, 0, 0), 1.0, (0, 0, 0), (0, 0, -1))
+    assert ok and rec[6] == 1.0 and rec[7] == 0.0 and rec[3:6] == [0.0, 0.0, 1.0]
+    # sphere behind the ray
+    assert not _sphere_hit(ob, (0, 0, 5), 1.0, (0, 0, 0), (0, 0, -1))[0]
+    # tangent ray: delta == 0 is a hit (delta < 0 is the miss test, object.defs.cc:48)
+    ok, rec = _sphere_hit(ob, (1, 0, -5), 1.0, (0, 0, 0), (0, 0, -1))
+    assert ok and rec[6] == 5.0
+    # interval is open: a root equal to Max is rejected, and falls back to the far root only if that surrounds
+    assert not _sphere_hit(ob, (0, 0, -5), 1.0, (0, 0, 0), (0, 0, -1), tmax=4.0)[0]
+    ok, rec = _sphere_hit(ob, (0, 0, -5), 1.0, (0, 0, 0), (0, 0, -1), tmin=4.0, tmax=7.0)
+    assert ok and rec[6] == 6.0 and rec[7] == 0.0
+    # tmin: roots <= 0.0001 are ignored (self-intersection guard, core.cc:243)
+    ok, rec = _sphere_hit(ob, (0, 0, -1), 1.0, (0, 0, 0), (0, 0, -1))
+    assert ok and rec[6] == 2.0
+    # zero direction: a == 0 -> NaN roots -> miss, no crash
+    assert not _sphere_hit(ob, (0, 0, -5), 1.0, (0, 0, 0), (0, 0, 0))[0]
+
+
+def test_collection_closest_hit_and_tie_rule(ob):
+    from tests.scenes import arrays
+    lam = (0, (0.5, 0.5, 0.5, 0.0))
+    objs, _ = arrays([((0, 0, -8), 1.0, lam), ((0, 0, -4), 1.0, lam), ((0, 0, -4), 1.0, lam), ((0, 0, 4), 1.0, lam)])
+    rec = (C.c_float * 8)()
+    idx = C.c_uint32(99)
+    ok = ob.lib().orc_world_intersect(objs.ctypes.data, len(objs), _f3((0, 0, 0)), _f3((0, 0, -1)), rec, C.byref(idx))
+    assert ok and rec[6] == 3.0 and idx.value == 1  # closest wins; of two identical spheres the first inserted wins
+    assert not ob.lib().orc_world_intersect(objs.ctypes.data, 0, _f3((0, 0, 0)), _f3((0, 0, -1)), rec, C.byref(idx))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# unit functions: Material::scatter
+# ---------------------------------------------------------------------------------------------------------------
+def _scatter(ob, mat, ro, rd, P, N, front, seed=1):
+    m = np.zeros(1, ob.MATERIAL_DTYPE)
+    m[0] = mat
+    L = ob.lib()
+    rng = L.orc_rng_new_mt(seed)
+    out = (C.c_float * 9)()
+    ok = L.orc_scatter(m.ctypes.data, _f3(ro), _f3(rd), _f3(P), _f3(N), int(front), rng, out)
+    nxt = L.orc_rng_double(rng)
+    L.orc_rng_free(rng)
+    return ok, list(out), nxt
+
+
+def _first_double(ob, seed=1):
+    L = ob.lib()
+    rng = L.orc_rng_new_mt(seed)
+    v = L.orc_rng_double(rng)
+    L.orc_rng_free(rng)
+    return v
+
+
+def test_scatter_lambertian(ob):
+    ok, out, _ = _scatter(ob, (0, (0.1, 0.2, 0.3, 0.0)), (0, 0, 0), (0, 0, -1), (0, 0, -4), (0, 0, 1), True)
+    assert ok and out[0:3] == [np.float32(0.1), np.float32(0.2), np.float32(0.3)] and out[3:6] == [0.0, 0.0, -4.0]
+    d = np.array(out[6:9]) - np.array([0, 0, 1.0])
+    assert abs(np.linalg.norm(d) - 1.0) < 1e-6  # N + unit vector
+
+
+def test_scatter_metal_reflects_and_absorbs(ob):
+    # mirror (fuzz 0): reflect(d, N) normalised
+    ok, out, _ = _scatter(ob, (1, (0.9, 0.9, 0.9, 0.0)), (0, 0, 0), (1, -1, 0), (1, -1, 0), (0, 1, 0), True)
+    assert ok and np.allclose(out[6:9], [2 ** -0.5, 2 ** -0.5, 0.0], atol=1e-7)
+    # grazing reflection with maximal fuzz is absorbed for some seeds: scatter returns nullopt (material.defs.cc:54)
+    res = [_scatter(ob, (1, (0.9, 0.9, 0.9, 1.0)), (0, 0, 0), (1, -1e-3, 0), (1, 0, 0), (0, 1, 0), True, seed=s)[0]
+           for s in range(1, 40)]
+    assert 0 in res and 1 in res
+
+
+def test_scatter_dielectric_short_circuit(ob):
+    """Total internal reflection draws no random number (`cannot_refract || schlick > rd()`, material.defs.cc:71-72)."""
+    glass = (2, (1.5, 0.0, 0.0, 0.0))
+    # inside the glass (front_face false -> eta = 1.5), grazing: eta * sin > 1
+    ok, out, nxt = _scatter(ob, glass, (0, 0, 0), (1, -0.2, 0), (0, 0, 0), (0, 1, 0), False)
+    assert ok and out[0:3] == [1.0, 1.0, 1.0]
+    assert nxt == _first_double(ob)  # generator untouched
+    u = np.array([1, -0.2, 0]) / np.linalg.norm([1, -0.2, 0])
+    assert np.allclose(out[6:9], u - 2 * np.dot(u, [0, 1, 0]) * np.array([0, 1, 0]), atol=1e-6)
+    # head-on from outside: refraction possible, exactly one draw consumed, straight through
+    ok, out, nxt = _scatter(ob, glass, (0, 0, 0), (0, -1, 0), (0, 0, 0), (0, 1, 0), True)
+    assert ok and nxt != _first_double(ob)
+    assert np.allclose(out[6:9], [0, -1, 0], atol=1e-6)
+
+
+def test_rgba_pack_edge_cases(ob):
+    def pack(r, g, b):
+        v = np.array([r, g, b], np.float32)
+        return ob.lib().orc_pack_rgba(v.ctypes.data)
+    assert pack(0, 0, 0) == 0xff000000
+    assert pack(1, 1, 1) == 0xffffffff and pack(50, 50, 50) == 0xffffffff  # clamp to 0.999 -> 255
+    assert pack(-1, float("nan"), 0.25) == 0xff800000  # negative and NaN -> 0; sqrt(0.25) * 256 = 128
+    assert pack(0.25, 0, 0) == 0xff000080  # little-endian: r is the low byte (0xAABBGGRR)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# depth handling and the instrumented BVH walk
+# ---------------------------------------------------------------------------------------------------------------
+def test_depth_semantics(ob, rtow):
+    """maxdepth 0 -> black; maxdepth 1 -> only rays that miss everything see the sky (core.cc:238-240)."""
+    for depth in (0, 1):
+        cam = ob.camera_setup(ob.camera_params(image_width=48, samples_per_pixel=2, max_depth=depth))
+        rgb, rgba, ctr = ob.render_rect_counter(cam, *rtow, 3, 0, 0, 48, 27, counters=True)
+        if depth == 0:
+            assert not rgb.any() and np.all(rgba == 0xff000000) and ctr["segments"] == 0
+        else:
+            assert ctr["segments"] == ctr["samples"] and rgb[0].min() > 0.4 and not rgb[-1].any()
+
+
+@pytest.mark.parametrize("leaf", [1, 2, 4])
+def test_bvh_walk_equals_linear_scan(ob, pkg, rtow, leaf):
+    """The instrumented BVH walk (build-side extension) returns the very same image as the reference's linear scan,
+    on the BVH the product builds."""
+    cam = ob.camera_setup(ob.camera_params(image_width=96, samples_per_pixel=4, max_depth=50))
+    lin, lin8, c0 = ob.render_rect_counter(cam, *rtow, 11, 0, 0, 96, 54, nthreads=8, counters=True)
+    bvh = pkg.bvh_build(rtow[0], leaf)
+    got, got8, c1 = ob.render_rect_counter(cam, *rtow, 11, 0, 0, 96, 54, nthreads=8, counters=True, bvh=bvh)
+    assert got.tobytes() == lin.tobytes() and got8.tobytes() == lin8.tobytes()
+    assert c1["segments"] == c0["segments"] and c0["sphere_tests"] == 488 * c0["segments"]
+    assert c1["node_tests"] > 0 and c1["sphere_tests"] < c0["sphere_tests"] // 20
