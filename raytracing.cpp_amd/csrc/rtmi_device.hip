@@ -32,6 +32,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rtmi_internal.h"
@@ -190,24 +191,43 @@ DEV void sphere_test(const float4 sph, const Trav& t, uint32_t slot, uint32_t ob
     }
 }
 
-template <int ACCEL, bool STATS>
+// BIG = false: the whole scene is staged into LDS and stack entries are packed into 16 bits (<= 8192 spheres).
+// BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
+//              32-bit entries (config 4: 100k spheres, 2.4 MB of spheres + 6.4 MB of nodes).
+template <int ACCEL, bool STATS, bool BIG>
 __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    // ---- stage the scene into LDS: coalesced 16-byte loads, one pass per array -----------------------------
-    uint4* lds_spheres = reinterpret_cast<uint4*>(lds_raw + P.lds_spheres);
-    uint4* lds_aux = reinterpret_cast<uint4*>(lds_raw + P.lds_aux);
-    uint4* lds_mats = reinterpret_cast<uint4*>(lds_raw + P.lds_mats);
-    uint4* lds_nodes = reinterpret_cast<uint4*>(lds_raw + P.lds_nodes);
-    uint16_t* lds_stack = reinterpret_cast<uint16_t*>(lds_raw + P.lds_stack);
-    for (uint32_t i = threadIdx.x; i < P.n_slots; i += blockDim.x) {
-        lds_spheres[i] = P.spheres[i];
-        lds_aux[i] = P.aux[i];
+    using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
+    StackT* lds_stack = reinterpret_cast<StackT*>(lds_raw + P.lds_stack);
+    const uint4* lds_spheres;
+    const uint4* lds_aux;
+    const uint4* lds_mats;
+    const uint4* lds_nodes;
+    if (BIG) {
+        lds_spheres = P.spheres;
+        lds_aux = P.aux;
+        lds_mats = P.mats;
+        lds_nodes = P.nodes;
+    } else {
+        // ---- stage the scene into LDS: coalesced 16-byte loads, one pass per array -------------------------
+        uint4* w_spheres = reinterpret_cast<uint4*>(lds_raw + P.lds_spheres);
+        uint4* w_aux = reinterpret_cast<uint4*>(lds_raw + P.lds_aux);
+        uint4* w_mats = reinterpret_cast<uint4*>(lds_raw + P.lds_mats);
+        uint4* w_nodes = reinterpret_cast<uint4*>(lds_raw + P.lds_nodes);
+        for (uint32_t i = threadIdx.x; i < P.n_slots; i += blockDim.x) {
+            w_spheres[i] = P.spheres[i];
+            w_aux[i] = P.aux[i];
+        }
+        for (uint32_t i = threadIdx.x; i < 2u * P.n_mats; i += blockDim.x) w_mats[i] = P.mats[i];
+        if (ACCEL == RTMI_ACCEL_BVH) {
+            for (uint32_t i = threadIdx.x; i < 4u * P.n_nodes; i += blockDim.x) w_nodes[i] = P.nodes[i];
+        }
+        __syncthreads();
+        lds_spheres = w_spheres;
+        lds_aux = w_aux;
+        lds_mats = w_mats;
+        lds_nodes = w_nodes;
     }
-    for (uint32_t i = threadIdx.x; i < 2u * P.n_mats; i += blockDim.x) lds_mats[i] = P.mats[i];
-    if (ACCEL == RTMI_ACCEL_BVH) {
-        for (uint32_t i = threadIdx.x; i < 4u * P.n_nodes; i += blockDim.x) lds_nodes[i] = P.nodes[i];
-    }
-    __syncthreads();
 
     const uint32_t lane = lane_id();
     const uint32_t total_lanes = gridDim.x * blockDim.x;
@@ -359,11 +379,11 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
                         if (hit0 && hit1) {
                             const bool swap = tn1 < tn0;
                             const uint32_t far_ref = swap ? ch0 : ch1;
-                            // stack entry: node index, or leaf as 0x8000 | (count-1) << 13 | first slot
-                            const uint32_t packed = (far_ref & kLeafBit)
+                            // 16-bit stack entry: node index, or leaf as 0x8000 | (count-1) << 13 | first slot
+                            const uint32_t packed = BIG ? far_ref : ((far_ref & kLeafBit)
                                 ? (0x8000u | ((((far_ref >> 24) & 0x7fu) - 1u) << 13) | (far_ref & 0x1fffu))
-                                : far_ref;
-                            lds_stack[t.sp * blockDim.x + threadIdx.x] = (uint16_t)packed;
+                                : far_ref);
+                            lds_stack[t.sp * blockDim.x + threadIdx.x] = (StackT)packed;
                             t.sp++;
                             t.cur = swap ? ch1 : ch0;
                         } else if (hit0) {
@@ -380,9 +400,9 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
                         } else {
                             t.sp--;
                             const uint32_t packed = lds_stack[t.sp * blockDim.x + threadIdx.x];
-                            t.cur = (packed & 0x8000u)
+                            t.cur = BIG ? packed : ((packed & 0x8000u)
                                 ? (kLeafBit | ((((packed >> 13) & 3u) + 1u) << 24) | (packed & 0x1fffu))
-                                : packed;
+                                : packed);
                         }
                     }
                 }
@@ -538,6 +558,7 @@ struct rtmi_scene {
     int device = 0;
     uint32_t accel = RTMI_ACCEL_BVH;
     bool collect_stats = false;
+    bool big = false; // scene read from HBM instead of LDS
     uint32_t n_objects = 0, n_mats = 0;
     Bvh bvh;
     // device buffers
@@ -565,9 +586,13 @@ namespace {
 
 using KernelFn = void (*)(const RtmiLaunch);
 
-KernelFn pick_kernel(uint32_t accel, bool stats) {
-    if (accel == RTMI_ACCEL_BVH) return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false>;
-    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BRUTE, true> : rtmi_trace_kernel<RTMI_ACCEL_BRUTE, false>;
+KernelFn pick_kernel(uint32_t accel, bool stats, bool big) {
+    if (accel == RTMI_ACCEL_BVH) {
+        if (big) return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, true> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, true>;
+        return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, false> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, false>;
+    }
+    if (big) return stats ? rtmi_trace_kernel<RTMI_ACCEL_BRUTE, true, true> : rtmi_trace_kernel<RTMI_ACCEL_BRUTE, false, true>;
+    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BRUTE, true, false> : rtmi_trace_kernel<RTMI_ACCEL_BRUTE, false, false>;
 }
 
 void free_scene(rtmi_scene* s) {
@@ -652,7 +677,7 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
 
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    KernelFn fn = pick_kernel(s->accel, s->collect_stats);
+    KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big);
     void* args[] = {&P};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
     HIP_TRY(hipEventRecord(s->ev1, stream));
@@ -730,8 +755,8 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     if (s->accel == RTMI_ACCEL_BVH) {
         build_bvh(objects, n_objects, opt.leaf_size ? opt.leaf_size : 2u, s->bvh);
         slot_object = s->bvh.slot_object;
-        if (s->bvh.nodes.size() >= 0x8000u || n_objects > 0x2000u) {
-            set_error("rtmi_scene_create: scene too large for the LDS-resident BVH kernel (max 8192 spheres)");
+        if (n_objects >= 0x00ffffffu) {
+            set_error("rtmi_scene_create: too many objects (leaf references hold 24-bit slots)");
             return fail(RTMI_ERR_UNSUPPORTED);
         }
     } else {
@@ -757,24 +782,31 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
         h_mats[2 * i + 1] = make_uint4(fbits(m.p[3]), 0u, 0u, 0u);
     }
 
-    // LDS carve-up
+    // LDS carve-up.  Small scenes live in LDS entirely (two workgroups per CU must fit: 80 KiB each); larger ones
+    // stay in HBM and only the traversal stack is in LDS.
     auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-    uint32_t off = 0;
-    s->lds_nodes = off;
-    off += (uint32_t)s->bvh.nodes.size() * 64u;
-    s->lds_spheres = off;
-    off += n_objects * 16u;
-    s->lds_aux = off;
-    off += n_objects * 16u;
-    s->lds_mats = off;
-    off += n_materials * 32u;
-    off = align16(off);
-    s->lds_stack = off;
     s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) : 0u;
-    off += s->stack_depth * s->block * 2u;
+    const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 32u;
+    const uint64_t small_total = scene_bytes + (uint64_t)s->stack_depth * s->block * 2u + 64u;
+    s->big = small_total > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u || n_objects > 0x2000u;
+    if (const char* e = std::getenv("RTMI_FORCE_BIG")) s->big = s->big || std::atoi(e) != 0;
+    uint32_t off = 0;
+    if (!s->big) {
+        s->lds_nodes = off;
+        off += (uint32_t)s->bvh.nodes.size() * 64u;
+        s->lds_spheres = off;
+        off += n_objects * 16u;
+        s->lds_aux = off;
+        off += n_objects * 16u;
+        s->lds_mats = off;
+        off += n_materials * 32u;
+        off = align16(off);
+    }
+    s->lds_stack = off;
+    off += s->stack_depth * s->block * (s->big ? 4u : 2u);
     s->lds_bytes = align16(off);
     if (s->lds_bytes > 160u * 1024u) {
-        set_error("rtmi_scene_create: scene does not fit the 160 KiB LDS of a CU");
+        set_error("rtmi_scene_create: traversal stack does not fit the 160 KiB LDS of a CU (BVH too deep)");
         return fail(RTMI_ERR_UNSUPPORTED);
     }
 
@@ -790,7 +822,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     HIP_TRY_S(upload(&s->d_nodes, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(rtmi_bvh_node)));
 
     // persistent grid: exactly as many workgroups as the device keeps resident
-    KernelFn fn = pick_kernel(s->accel, s->collect_stats);
+    KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big);
     HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)s->lds_bytes));
     int per_cu = 0;
