@@ -54,7 +54,7 @@ struct RtmiLaunch {
     uint32_t n_pad_classes;
     float pad_eps, pad_floor;
     // LDS carve-up (byte offsets)
-    uint32_t lds_spheres, lds_aux, lds_mats, lds_nodes, lds_stack, stack_depth;
+    uint32_t lds_spheres, lds_aux, lds_mats, lds_nodes, lds_stack, stack_depth, lds_att;
     // image rows handled by this launch
     uint32_t y_first, block_rows, block_stride, n_local_rows;
     uint32_t tiles_x, n_work; // work index space = tiles * 64
@@ -68,6 +68,18 @@ struct RtmiLaunch {
 };
 
 #define DEV static __device__ __forceinline__
+
+// In-kernel stamps (diagnostic build only, -DRTMI_PROF): s_memtime deltas per phase of the v1 kernel, summed per wave
+// into stats[8 + i].  Never compiled into the shipped library.
+#ifdef RTMI_PROF
+#define PF_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0, pf7 = 0, pf8 = 0, pf9 = 0, pf10 = 0, pf11 = 0;
+#define PF_MARK(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - pf_t; pf_t = n_; } while (0)
+#define PF_COUNT(acc) do { acc += 1; } while (0)
+#else
+#define PF_DECL
+#define PF_MARK(acc) do { } while (0)
+#define PF_COUNT(acc) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // vec3 with glm's published semantics (glm is an un-vendored dependency of the reference)
@@ -149,6 +161,7 @@ DEV V3 random_unit_vector(Rng& r, uint64_t seed) {
 // lane state machine
 // ---------------------------------------------------------------------------------------------------------
 enum : uint32_t { PH_FETCH = 0, PH_GEN = 1, PH_TRAV = 2, PH_SHADE = 3, PH_DONE = 4 };
+constexpr uint32_t kAttLds = 8; // attenuation handles kept in LDS per lane; deeper ones go to a per-lane L2-resident strip
 
 struct Trav { // per-segment traversal state
     V3 o, d;
@@ -199,6 +212,7 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
     StackT* lds_stack = reinterpret_cast<StackT*>(lds_raw + P.lds_stack);
+    uint16_t* lds_att = reinterpret_cast<uint16_t*>(lds_raw + P.lds_att);
     const uint4* lds_spheres;
     const uint4* lds_aux;
     const uint4* lds_mats;
@@ -230,7 +244,6 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
     }
 
     const uint32_t lane = lane_id();
-    const uint32_t total_lanes = gridDim.x * blockDim.x;
     const uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t W = P.cam.img_width;
     const uint32_t spp = P.cam.samples_per_pixel;
@@ -241,7 +254,21 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
     Rng rng{};
     Trav t{};
     uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0;
+    PF_DECL
 
+    // attenuation chain: material handles of the non-dielectric bounces of the live path.  The first kAttLds live in
+    // LDS; deeper ones (paths trapped inside the ground sphere run to maxdepth) in a per-lane contiguous strip that
+    // stays L2-resident, so the chain costs no HBM traffic.
+    const uint32_t maxdepth = P.cam.maxdepth;
+    auto att_push = [&](uint32_t h) {
+        if (!BIG && natt < kAttLds) lds_att[natt * blockDim.x + threadIdx.x] = (uint16_t)h;
+        else P.att_stack[(size_t)glane * maxdepth + natt] = h;
+        natt++;
+    };
+    auto att_get = [&](uint32_t q) -> uint32_t {
+        if (!BIG && q < kAttLds) return lds_att[q * blockDim.x + threadIdx.x];
+        return P.att_stack[(size_t)glane * maxdepth + q];
+    };
     auto begin_segment = [&](V3 o, V3 d) {
         t.o = o;
         t.d = d;
@@ -270,6 +297,8 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
     };
 
     for (;;) {
+        PF_MARK(pf9);
+        PF_COUNT(pf10);
         // ---- FETCH: one wave-aggregated atomic hands out consecutive indices of the 8x8-tiled pixel space -----
         while (phase == PH_FETCH) {
             const uint64_t need = __ballot(1);
@@ -293,6 +322,7 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
             }
         }
         if (__ballot(phase != PH_DONE) == 0ull) break;
+        PF_MARK(pf0);
 
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
         if (phase == PH_GEN) {
@@ -331,16 +361,22 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
             }
         }
 
+        PF_MARK(pf1);
         // ---- TRAVERSE ---------------------------------------------------------------------------------------------
         if (ACCEL == RTMI_ACCEL_BVH) {
+            // Two kinds of step: an internal node (two slab tests) or a leaf (its spheres).  Each iteration the wave
+            // runs only the kind that holds more of its traversing lanes; the other lanes keep their place.
             for (;;) {
-                const uint64_t trav = __ballot(phase == PH_TRAV);
-                if (trav == 0ull) break;
+                const bool at_leaf = (t.cur & kLeafBit) != 0u;
+                const uint64_t m_node = __ballot(phase == PH_TRAV && !at_leaf);
+                const uint64_t m_leaf = __ballot(phase == PH_TRAV && at_leaf);
+                if ((m_node | m_leaf) == 0ull) break;
+                PF_COUNT(pf11);
                 const uint32_t nwait = (uint32_t)__popcll(__ballot(phase == PH_SHADE));
                 if (nwait >= P.wait_thresh) break;
-                if (phase == PH_TRAV) {
-                    bool pop = false;
-                    if (t.cur & kLeafBit) {
+                bool pop = false;
+                if (__popcll(m_leaf) > __popcll(m_node)) {
+                    if (phase == PH_TRAV && at_leaf) {
                         const uint32_t first = t.cur & 0x00ffffffu, cnt = (t.cur >> 24) & 0x7fu;
                         for (uint32_t q = 0; q < cnt; ++q) {
                             const uint4 raw = lds_spheres[first + q];
@@ -350,60 +386,59 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
                         }
                         if (STATS) st_sphere += cnt;
                         pop = true;
-                    } else {
-                        const uint4 n0 = lds_nodes[4u * t.cur + 0u];
-                        const uint4 n1 = lds_nodes[4u * t.cur + 1u];
-                        const uint4 n2 = lds_nodes[4u * t.cur + 2u];
-                        const uint4 n3 = lds_nodes[4u * t.cur + 3u];
-                        // rtmi_bvh_node: ctr[2][3] | half[2][3] | child[2] | reserved[2]
-                        const float c0x = __uint_as_float(n0.x), c0y = __uint_as_float(n0.y), c0z = __uint_as_float(n0.z);
-                        const float c1x = __uint_as_float(n0.w), c1y = __uint_as_float(n1.x), c1z = __uint_as_float(n1.y);
-                        const float h0x = __uint_as_float(n1.z), h0y = __uint_as_float(n1.w), h0z = __uint_as_float(n2.x);
-                        const float h1x = __uint_as_float(n2.y), h1y = __uint_as_float(n2.z), h1z = __uint_as_float(n2.w);
-                        const float ax = __builtin_fabsf(t.inv.x), ay = __builtin_fabsf(t.inv.y), az = __builtin_fabsf(t.inv.z);
-                        // slab test in centre/half form: the pad rides in the FMA of the half extent
-                        const float tc0x = __builtin_fmaf(c0x, t.inv.x, t.oinv.x), th0x = __builtin_fmaf(h0x, ax, t.pinv.x);
-                        const float tc0y = __builtin_fmaf(c0y, t.inv.y, t.oinv.y), th0y = __builtin_fmaf(h0y, ay, t.pinv.y);
-                        const float tc0z = __builtin_fmaf(c0z, t.inv.z, t.oinv.z), th0z = __builtin_fmaf(h0z, az, t.pinv.z);
-                        const float tc1x = __builtin_fmaf(c1x, t.inv.x, t.oinv.x), th1x = __builtin_fmaf(h1x, ax, t.pinv.x);
-                        const float tc1y = __builtin_fmaf(c1y, t.inv.y, t.oinv.y), th1y = __builtin_fmaf(h1y, ay, t.pinv.y);
-                        const float tc1z = __builtin_fmaf(c1z, t.inv.z, t.oinv.z), th1z = __builtin_fmaf(h1z, az, t.pinv.z);
-                        // fmaxf/fminf drop a NaN operand (0 * inf on an axis-parallel ray), which keeps the test conservative
-                        const float tn0 = fmaxf(fmaxf(tc0x - th0x, tc0y - th0y), fmaxf(tc0z - th0z, 0.0001f));
-                        const float tf0 = fminf(fminf(tc0x + th0x, tc0y + th0y), fminf(tc0z + th0z, t.tbest));
-                        const float tn1 = fmaxf(fmaxf(tc1x - th1x, tc1y - th1y), fmaxf(tc1z - th1z, 0.0001f));
-                        const float tf1 = fminf(fminf(tc1x + th1x, tc1y + th1y), fminf(tc1z + th1z, t.tbest));
-                        if (STATS) st_node += 2;
-                        const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
-                        const uint32_t ch0 = n3.x, ch1 = n3.y;
-                        if (hit0 && hit1) {
-                            const bool swap = tn1 < tn0;
-                            const uint32_t far_ref = swap ? ch0 : ch1;
+                    }
+                } else if (phase == PH_TRAV && !at_leaf) {
+                    const uint4 n0 = lds_nodes[4u * t.cur + 0u];
+                    const uint4 n1 = lds_nodes[4u * t.cur + 1u];
+                    const uint4 n2 = lds_nodes[4u * t.cur + 2u];
+                    const uint4 n3 = lds_nodes[4u * t.cur + 3u];
+                    // rtmi_bvh_node: ctr[2][3] | half[2][3] | child[2] | reserved[2]
+                    const float c0x = __uint_as_float(n0.x), c0y = __uint_as_float(n0.y), c0z = __uint_as_float(n0.z);
+                    const float c1x = __uint_as_float(n0.w), c1y = __uint_as_float(n1.x), c1z = __uint_as_float(n1.y);
+                    const float h0x = __uint_as_float(n1.z), h0y = __uint_as_float(n1.w), h0z = __uint_as_float(n2.x);
+                    const float h1x = __uint_as_float(n2.y), h1y = __uint_as_float(n2.z), h1z = __uint_as_float(n2.w);
+                    const float ax = __builtin_fabsf(t.inv.x), ay = __builtin_fabsf(t.inv.y), az = __builtin_fabsf(t.inv.z);
+                    // slab test in centre/half form: the pad rides in the FMA of the half extent
+                    const float tc0x = __builtin_fmaf(c0x, t.inv.x, t.oinv.x), th0x = __builtin_fmaf(h0x, ax, t.pinv.x);
+                    const float tc0y = __builtin_fmaf(c0y, t.inv.y, t.oinv.y), th0y = __builtin_fmaf(h0y, ay, t.pinv.y);
+                    const float tc0z = __builtin_fmaf(c0z, t.inv.z, t.oinv.z), th0z = __builtin_fmaf(h0z, az, t.pinv.z);
+                    const float tc1x = __builtin_fmaf(c1x, t.inv.x, t.oinv.x), th1x = __builtin_fmaf(h1x, ax, t.pinv.x);
+                    const float tc1y = __builtin_fmaf(c1y, t.inv.y, t.oinv.y), th1y = __builtin_fmaf(h1y, ay, t.pinv.y);
+                    const float tc1z = __builtin_fmaf(c1z, t.inv.z, t.oinv.z), th1z = __builtin_fmaf(h1z, az, t.pinv.z);
+                    // fmaxf/fminf drop a NaN operand (0 * inf on an axis-parallel ray), which keeps the test conservative
+                    const float tn0 = fmaxf(fmaxf(tc0x - th0x, tc0y - th0y), fmaxf(tc0z - th0z, 0.0001f));
+                    const float tf0 = fminf(fminf(tc0x + th0x, tc0y + th0y), fminf(tc0z + th0z, t.tbest));
+                    const float tn1 = fmaxf(fmaxf(tc1x - th1x, tc1y - th1y), fmaxf(tc1z - th1z, 0.0001f));
+                    const float tf1 = fminf(fminf(tc1x + th1x, tc1y + th1y), fminf(tc1z + th1z, t.tbest));
+                    if (STATS) st_node += 2;
+                    const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
+                    const uint32_t ch0 = n3.x, ch1 = n3.y;
+                    if (hit0 || hit1) {
+                        const bool both = hit0 && hit1;
+                        const bool take1 = both ? (tn1 < tn0) : hit1;
+                        if (both) {
+                            const uint32_t far_ref = take1 ? ch0 : ch1;
                             // 16-bit stack entry: node index, or leaf as 0x8000 | (count-1) << 13 | first slot
                             const uint32_t packed = BIG ? far_ref : ((far_ref & kLeafBit)
                                 ? (0x8000u | ((((far_ref >> 24) & 0x7fu) - 1u) << 13) | (far_ref & 0x1fffu))
                                 : far_ref);
                             lds_stack[t.sp * blockDim.x + threadIdx.x] = (StackT)packed;
                             t.sp++;
-                            t.cur = swap ? ch1 : ch0;
-                        } else if (hit0) {
-                            t.cur = ch0;
-                        } else if (hit1) {
-                            t.cur = ch1;
-                        } else {
-                            pop = true;
                         }
+                        t.cur = take1 ? ch1 : ch0;
+                    } else {
+                        pop = true;
                     }
-                    if (pop) {
-                        if (t.sp == 0) {
-                            phase = PH_SHADE;
-                        } else {
-                            t.sp--;
-                            const uint32_t packed = lds_stack[t.sp * blockDim.x + threadIdx.x];
-                            t.cur = BIG ? packed : ((packed & 0x8000u)
-                                ? (kLeafBit | ((((packed >> 13) & 3u) + 1u) << 24) | (packed & 0x1fffu))
-                                : packed);
-                        }
+                }
+                if (pop) {
+                    if (t.sp == 0) {
+                        phase = PH_SHADE;
+                    } else {
+                        t.sp--;
+                        const uint32_t packed = lds_stack[t.sp * blockDim.x + threadIdx.x];
+                        t.cur = BIG ? packed : ((packed & 0x8000u)
+                            ? (kLeafBit | ((((packed >> 13) & 3u) + 1u) << 24) | (packed & 0x1fffu))
+                            : packed);
                     }
                 }
             }
@@ -424,6 +459,7 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
             }
         }
 
+        PF_MARK(pf2);
         // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
         if (phase == PH_SHADE) {
             bool ended = false;
@@ -446,16 +482,22 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
                 const V3 albedo = mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w));
                 V3 sd = mk(0.0f, 0.0f, 0.0f);
                 bool scattered = true;
-                if (kind == 0u) { // Material_Lambertian::scatter, material.defs.cc:31-42
-                    sd = vadd(N, random_unit_vector(rng, P.seed));
-                    const float eps = 1e-8f; // near_zero, ray.tracer.math.hpp:16-19
-                    if (__builtin_fabsf(sd.x) < eps && __builtin_fabsf(sd.y) < eps && __builtin_fabsf(sd.z) < eps) sd = N;
-                } else if (kind == 1u) { // Material_Metallic::scatter, material.defs.cc:44-55
-                    const float fuzz = __uint_as_float(m1.x);
-                    V3 refl = vreflect(t.d, N);
-                    refl = vadd(vnormalize(refl), vscale(random_unit_vector(rng, P.seed), fuzz));
-                    scattered = vdot(refl, N) > 0.0f;
-                    sd = refl;
+                PF_MARK(pf3);
+                if (kind != 2u) {
+                    // Lambertian (material.defs.cc:31-42) and Metallic (:44-55) share ONE rejection loop for their
+                    // random_unit_vector(): the wave pays the longest run of rejections once, not once per material.
+                    V3 rn = mk(0.0f, 0.0f, 0.0f);
+                    if (kind == 1u) rn = vnormalize(vreflect(t.d, N));
+                    const V3 u = random_unit_vector(rng, P.seed);
+                    if (kind == 0u) {
+                        sd = vadd(N, u);
+                        const float eps = 1e-8f; // near_zero, ray.tracer.math.hpp:16-19
+                        if (__builtin_fabsf(sd.x) < eps && __builtin_fabsf(sd.y) < eps && __builtin_fabsf(sd.z) < eps) sd = N;
+                    } else {
+                        sd = vadd(rn, vscale(u, __uint_as_float(m1.x)));
+                        scattered = vdot(sd, N) > 0.0f;
+                    }
+                    PF_MARK(pf4);
                 } else { // Material_Dielectric::scatter, material.defs.cc:57-87
                     const float ri = __uint_as_float(m0.y);
                     const float eta = front ? (1.0f / ri) : ri;
@@ -475,14 +517,13 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
                         reflect_it = (double)schlick > u;
                     }
                     sd = reflect_it ? vreflect(unit_dir, N) : vrefract(unit_dir, N, eta);
+                    PF_MARK(pf6);
                 }
+                PF_MARK(pf8);
                 if (!scattered) {
                     ended = true; // absorbed: compute_color returns 0 (core.cc:251)
                 } else {
-                    if (kind != 2u) { // dielectric attenuation is (1,1,1): multiplying by it is exact, skip
-                        P.att_stack[(size_t)natt * total_lanes + glane] = mh;
-                        natt++;
-                    }
+                    if (kind != 2u) att_push(mh); // dielectric attenuation is (1,1,1): multiplying by it is exact, skip
                     depth_left--;
                     if (depth_left == 0) {
                         ended = true; // the next compute_color call returns 0 (core.cc:238-240)
@@ -497,12 +538,13 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
                 const float tt = 0.5f * (unit_dir.y + 1.0f);
                 color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
                 for (uint32_t q = natt; q-- > 0u;) {
-                    const uint32_t mh = P.att_stack[(size_t)q * total_lanes + glane];
-                    const uint4 m0 = lds_mats[2u * mh];
+                    const uint4 m0 = lds_mats[2u * att_get(q)];
                     color = vmul(mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w)), color);
                 }
                 ended = true;
+                PF_MARK(pf7);
             }
+            PF_MARK(pf8);
             if (ended) {
                 // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
                 sum = vadd(sum, color);
@@ -533,6 +575,14 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
         }
     }
 
+#ifdef RTMI_PROF
+    PF_MARK(pf9);
+    if (lane == 0) {
+        atomicAdd(&P.stats[8], pf0); atomicAdd(&P.stats[9], pf1); atomicAdd(&P.stats[10], pf2); atomicAdd(&P.stats[11], pf3);
+        atomicAdd(&P.stats[12], pf4); atomicAdd(&P.stats[13], pf5); atomicAdd(&P.stats[14], pf6); atomicAdd(&P.stats[15], pf7);
+        atomicAdd(&P.stats[16], pf8); atomicAdd(&P.stats[17], pf9); atomicAdd(&P.stats[18], pf10); atomicAdd(&P.stats[19], pf11);
+    }
+#endif
     if (STATS) {
         atomicAdd(&P.stats[0], (unsigned long long)st_samples);
         atomicAdd(&P.stats[1], (unsigned long long)st_segments);
@@ -575,7 +625,8 @@ struct rtmi_scene {
     // launch geometry
     uint32_t block = 512, grid = 0, lds_bytes = 0, stack_depth = 0;
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
-    uint32_t wait_thresh = 64;
+    uint32_t wait_thresh = 56; // lanes waiting for shading that end a traversal round (A/B on MI355X: 56 best)
+    uint32_t lds_att = 0;
     hipStream_t stream = nullptr; // private stream of the blocking entry point
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -586,13 +637,14 @@ namespace {
 
 using KernelFn = void (*)(const RtmiLaunch);
 
+template <int ACCEL>
+KernelFn pick_variant(bool stats, bool big) {
+    if (big) return stats ? rtmi_trace_kernel<ACCEL, true, true> : rtmi_trace_kernel<ACCEL, false, true>;
+    return stats ? rtmi_trace_kernel<ACCEL, true, false> : rtmi_trace_kernel<ACCEL, false, false>;
+}
+
 KernelFn pick_kernel(uint32_t accel, bool stats, bool big) {
-    if (accel == RTMI_ACCEL_BVH) {
-        if (big) return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, true> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, true>;
-        return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, false> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, false>;
-    }
-    if (big) return stats ? rtmi_trace_kernel<RTMI_ACCEL_BRUTE, true, true> : rtmi_trace_kernel<RTMI_ACCEL_BRUTE, false, true>;
-    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BRUTE, true, false> : rtmi_trace_kernel<RTMI_ACCEL_BRUTE, false, false>;
+    return accel == RTMI_ACCEL_BVH ? pick_variant<RTMI_ACCEL_BVH>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE>(stats, big);
 }
 
 void free_scene(rtmi_scene* s) {
@@ -655,6 +707,7 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     P.lds_mats = s->lds_mats;
     P.lds_nodes = s->lds_nodes;
     P.lds_stack = s->lds_stack;
+    P.lds_att = s->lds_att;
     P.stack_depth = s->stack_depth;
     P.y_first = y_first;
     P.block_rows = block_rows;
@@ -788,7 +841,8 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) : 0u;
     const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 32u;
     const uint64_t small_total = scene_bytes + (uint64_t)s->stack_depth * s->block * 2u + 64u;
-    s->big = small_total > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u || n_objects > 0x2000u;
+    s->big = small_total + kAttLds * s->block * 2u > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u ||
+             n_objects > 0x2000u || n_materials > 0x10000u;
     if (const char* e = std::getenv("RTMI_FORCE_BIG")) s->big = s->big || std::atoi(e) != 0;
     uint32_t off = 0;
     if (!s->big) {
@@ -804,6 +858,9 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     }
     s->lds_stack = off;
     off += s->stack_depth * s->block * (s->big ? 4u : 2u);
+    off = align16(off);
+    s->lds_att = off;
+    if (!s->big) off += kAttLds * s->block * 2u;
     s->lds_bytes = align16(off);
     if (s->lds_bytes > 160u * 1024u) {
         set_error("rtmi_scene_create: traversal stack does not fit the 160 KiB LDS of a CU (BVH too deep)");
@@ -838,8 +895,8 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     s->grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
 
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_counter), 16));
-    HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 4 * sizeof(unsigned long long)));
-    HIP_TRY_S(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 32 * sizeof(unsigned long long)));
+    HIP_TRY_S(hipMemset(s->d_stats, 0, 32 * sizeof(unsigned long long)));
     const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * s->grid * s->block * sizeof(uint32_t));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_att), att_bytes));
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -966,3 +1023,11 @@ extern "C" int rtmi_scene_last_kernel_ms(rtmi_scene* s, float* ms_out) {
     HIP_TRY(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
     return RTMI_OK;
 }
+
+#ifdef RTMI_PROF
+extern "C" int rtmi_prof_read(rtmi_scene* s, unsigned long long* out32) {
+    hipSetDevice(s->device);
+    hipDeviceSynchronize();
+    return hipMemcpy(out32, s->d_stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -1,0 +1,28 @@
+"""Diagnostic build (-DRTMI_PROF) of the v1 kernel with s_memtime stamps: where a wave spends its cycles."""
+import ctypes as C, os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rtmi_loader
+pkg = rtmi_loader.load()
+prof_lib = os.path.join(os.path.dirname(pkg.LIB_PATH), "librtmi_prof.so")
+if "--build" in sys.argv:
+    cmd = ["/opt/rocm/bin/hipcc"] + pkg.HIPCC_FLAGS + ["-DRTMI_PROF", "-I", "include", "-o", prof_lib] + pkg.CSRC
+    subprocess.run(cmd, check=True)
+    print("built", prof_lib); sys.exit(0)
+pkg.LIB_PATH = prof_lib
+os.environ.setdefault("RTMI_WAIT_THRESH", "56")
+w, spp = int(sys.argv[1]), int(sys.argv[2])
+cam = pkg.camera_setup(pkg.camera_params(image_width=w, samples_per_pixel=spp, max_depth=50))
+objs, mats = pkg.make_world_spheres(12345)
+with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
+    sc.render_rows(0, cam.img_height, 7)
+    ms = sc.last_kernel_ms()
+    out = (C.c_ulonglong * 32)()
+    pkg.lib().rtmi_prof_read(sc._h, out)
+names = ["fetch", "gen", "traverse", "hitrec", "lambert", "metal", "dielectric", "miss", "shade-glue", "loop-glue", "#rounds", "#trav-iters"]
+v = [int(x) for x in out[8:20]]
+tot = sum(v[:10])
+print(f"kernel {ms:.1f} ms; stamped cycles (sum over waves) {tot:.3e}")
+for n, x in zip(names, v):
+    print(f"  {n:12s} {x:16d}  {100.0*x/tot if n[0] != '#' else 0:6.2f} %")
+print(f"  trav iters per round: {v[11]/max(1,v[10]):.2f}; cycles per trav iter: {v[2]/max(1,v[11]):.1f}; cycles per round: {tot/max(1,v[10]):.1f}")
