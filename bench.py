@@ -31,6 +31,31 @@ BLOCK_ROWS = 8
 VALU_PEAK_TFLOPS = 78.6
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes expose all
+    host CPUs in the mask but grant a share of them)."""
+    hw = os.cpu_count() or 1
+    try:
+        hw = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    hw = min(hw, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    hw = min(hw, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return hw
+
+
 def flops_per_sample(ctr):
     """S * (T_sphere * 23 + T_node * 30 + 70), all per-sample means."""
     n = float(ctr["samples"])
@@ -142,7 +167,6 @@ def main():
         n_chk = 48
         xs, ys = rng.integers(0, W, n_chk), rng.integers(0, H, n_chk)
         worst = 0.0
-        nthreads = max(1, (os.cpu_count() or 1) - (2 if (os.cpu_count() or 1) > 6 else 0))
         for x, y in zip(xs, ys):
             want, _ = ob.render_rect_counter(ocam, objs, mats, RENDER_SEED, int(x), int(y), int(x) + 1, int(y) + 1)
             worst = max(worst, float(np.abs(frame_h[y, x] - want[0, 0]).max()))
@@ -187,11 +211,7 @@ def main():
         }
         # ---- CPU baseline: the oracle, reference-shaped job system, on this host's cores -----------------------
         if world == 1 and not args.no_cpu_baseline:
-            hw = os.cpu_count() or 1
-            try:
-                hw = len(os.sched_getaffinity(0))
-            except Exception:
-                pass
+            hw = usable_cpus()
             threads = hw - 2 if hw > 6 else hw  # src/main.cc:608-611
             secs, n = ob.bench_mt(ocam, objs, mats, SCENE_SEED, args.cpu_stride, threads)
             secs1, n1 = ob.bench_mt(ocam, objs, mats, SCENE_SEED, args.cpu_stride * 6, 1)

@@ -1,7 +1,8 @@
 """ctypes binding of the CPU oracle (oracle/rt_oracle.c).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg, never by the product package.  PARITY UNPINNED (see rt_oracle.h).
+cpu_baseline leg, never by the product package.  Parity is pinned only by the four reference pixels of
+SURVEY.md 8(c); otherwise unpinned (see rt_oracle.h).
 """
 import ctypes as C
 import os

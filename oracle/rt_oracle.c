@@ -1,9 +1,10 @@
 /*
  * rt_oracle.c -- CPU oracle: plain-C restatement of the reference's per-pixel path tracer.
  *
- * TEST INFRASTRUCTURE ONLY (see rt_oracle.h).  PARITY UNPINNED: the reference holds no golden
- * vectors for this path and cannot be built in this image; every function below cites the
- * reference file:line whose arithmetic it restates.
+ * TEST INFRASTRUCTURE ONLY (see rt_oracle.h).  PARITY UNPINNED beyond the four reference pixels of
+ * SURVEY.md 8(c) (reproduced bit for bit): the reference holds no golden vectors for this path and
+ * cannot be built in this image; every function below cites the reference file:line whose
+ * arithmetic it restates.
  *
  * Build: gcc -O3 -ffp-contract=off -fno-fast-math (baseline x86-64, SSE2 scalar fp32/fp64, no FMA),
  * which is what the reference's CMake Release build produces for these TUs.  Every float operation is

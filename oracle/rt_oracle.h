@@ -6,13 +6,13 @@
  * load this library; the product (raytracing.cpp_amd/, include/rtmi.h) never
  * links, imports or calls it.
  *
- * PARITY UNPINNED: the reference (adihodos/raytracing.cpp) ships no tests, no
- * golden vectors and no fixtures for this path, and its hot-path TUs cannot be
- * built in this image (they need glm, tl::optional, strong_type and
- * reflect-cpp, none of which is vendored or installed).  This file is a
- * from-scratch restatement in plain C of the reference's arithmetic, each
- * function citing the reference file:line it follows; the glm operations are
- * restated from glm's published definitions (pinned by the reference's
+ * PARITY: the reference (adihodos/raytracing.cpp) ships no tests, no golden vectors and no fixtures for this path,
+ * and its hot-path TUs cannot be built in this image (they need glm, tl::optional, strong_type and reflect-cpp, none
+ * of which is vendored or installed; stand-in headers are not allowed).  The only outputs of the reference itself
+ * that exist are the four RGBA8 pixels recorded in SURVEY.md section 8(c); the mt19937 path of this file reproduces
+ * them bit for bit (tests/golden/reference_pixels.json).  Beyond those four vectors PARITY IS UNPINNED: this file is
+ * a from-scratch restatement in plain C of the reference's arithmetic, each function citing the reference file:line
+ * it follows; the glm operations are restated from glm's published definitions (pinned by the reference's
  * CMakeLists.txt:55 to g-truc/glm@bf71a834).
  */
 #ifndef RT_ORACLE_H
