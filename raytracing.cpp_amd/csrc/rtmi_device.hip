@@ -57,7 +57,8 @@ struct RtmiLaunch {
     uint32_t lds_spheres, lds_aux, lds_mats, lds_nodes, lds_stack, stack_depth, lds_att;
     // image rows handled by this launch
     uint32_t y_first, block_rows, block_stride, n_local_rows;
-    uint32_t tiles_x, n_work; // work index space = tiles * 64
+    uint32_t tiles_x, tiles_y, n_work; // work index space = tiles * 64
+    uint32_t top_down;
     uint32_t wait_thresh;     // leave the traversal loop when this many lanes of a wave wait for shading
     uint64_t seed;
     float* out_rgb;
@@ -72,13 +73,15 @@ struct RtmiLaunch {
 // In-kernel stamps (diagnostic build only, -DRTMI_PROF): s_memtime deltas per phase of the v1 kernel, summed per wave
 // into stats[8 + i].  Never compiled into the shipped library.
 #ifdef RTMI_PROF
-#define PF_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0, pf7 = 0, pf8 = 0, pf9 = 0, pf10 = 0, pf11 = 0;
+#define PF_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0, pf7 = 0, pf8 = 0, pf9 = 0, pf10 = 0, pf11 = 0, pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0, pl4 = 0, pl5 = 0, pl6 = 0, pl7 = 0;
 #define PF_MARK(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - pf_t; pf_t = n_; } while (0)
 #define PF_COUNT(acc) do { acc += 1; } while (0)
+#define PF_LANES(acc, mask) do { acc += (unsigned long long)__popcll(mask); } while (0)
 #else
 #define PF_DECL
 #define PF_MARK(acc) do { } while (0)
 #define PF_COUNT(acc) do { } while (0)
+#define PF_LANES(acc, mask) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -208,7 +211,7 @@ DEV void sphere_test(const float4 sph, const Trav& t, uint32_t slot, uint32_t ob
 // BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
 //              32-bit entries (config 4: 100k spheres, 2.4 MB of spheres + 6.4 MB of nodes).
 template <int ACCEL, bool STATS, bool BIG>
-__global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
+__global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
     StackT* lds_stack = reinterpret_cast<StackT*>(lds_raw + P.lds_stack);
@@ -311,7 +314,8 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
                 phase = PH_DONE;
             } else {
                 const uint32_t tile = idx >> 6, j = idx & 63u;
-                const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+                // bottom rows first: they cost ~5x a sky row, so the tail of the launch is made of cheap pixels
+                const uint32_t tx = tile % P.tiles_x, ty = P.top_down ? tile / P.tiles_x : P.tiles_y - 1u - tile / P.tiles_x;
                 px = tx * 8u + (j & 7u);
                 ply = ty * 8u + (j >> 3);
                 if (px < W && ply < P.n_local_rows) {
@@ -323,6 +327,7 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
         }
         if (__ballot(phase != PH_DONE) == 0ull) break;
         PF_MARK(pf0);
+        PF_LANES(pl5, __ballot(phase == PH_GEN));
 
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
         if (phase == PH_GEN) {
@@ -372,10 +377,13 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
                 const uint64_t m_leaf = __ballot(phase == PH_TRAV && at_leaf);
                 if ((m_node | m_leaf) == 0ull) break;
                 PF_COUNT(pf11);
-                const uint32_t nwait = (uint32_t)__popcll(__ballot(phase == PH_SHADE));
-                if (nwait >= P.wait_thresh) break;
+                if (__popcll(m_leaf) > __popcll(m_node)) { PF_COUNT(pl0); PF_LANES(pl1, m_leaf); } else { PF_LANES(pl2, m_node); }
+                // leave when wait_thresh lanes wait for shading; the stragglers keep their state and go on next round
+                // (A/B on MI355X: counting finished lanes as waiting too was 0-5 % slower)
+                const uint32_t n_leaf = (uint32_t)__popcll(m_leaf), n_node = (uint32_t)__popcll(m_node);
+                if ((uint32_t)__popcll(__ballot(phase == PH_SHADE)) >= P.wait_thresh) break;
                 bool pop = false;
-                if (__popcll(m_leaf) > __popcll(m_node)) {
+                if (n_leaf > n_node) {
                     if (phase == PH_TRAV && at_leaf) {
                         const uint32_t first = t.cur & 0x00ffffffu, cnt = (t.cur >> 24) & 0x7fu;
                         for (uint32_t q = 0; q < cnt; ++q) {
@@ -460,6 +468,9 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
         }
 
         PF_MARK(pf2);
+        PF_LANES(pl3, __ballot(phase == PH_SHADE));
+        PF_LANES(pl4, __ballot(phase == PH_SHADE && t.best == ~0u));
+        PF_LANES(pl7, __ballot(phase == PH_DONE));
         // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
         if (phase == PH_SHADE) {
             bool ended = false;
@@ -581,6 +592,8 @@ __global__ void __launch_bounds__(512) rtmi_trace_kernel(const RtmiLaunch P) {
         atomicAdd(&P.stats[8], pf0); atomicAdd(&P.stats[9], pf1); atomicAdd(&P.stats[10], pf2); atomicAdd(&P.stats[11], pf3);
         atomicAdd(&P.stats[12], pf4); atomicAdd(&P.stats[13], pf5); atomicAdd(&P.stats[14], pf6); atomicAdd(&P.stats[15], pf7);
         atomicAdd(&P.stats[16], pf8); atomicAdd(&P.stats[17], pf9); atomicAdd(&P.stats[18], pf10); atomicAdd(&P.stats[19], pf11);
+        atomicAdd(&P.stats[20], pl0); atomicAdd(&P.stats[21], pl1); atomicAdd(&P.stats[22], pl2); atomicAdd(&P.stats[23], pl3);
+        atomicAdd(&P.stats[24], pl4); atomicAdd(&P.stats[25], pl5); atomicAdd(&P.stats[26], pl6); atomicAdd(&P.stats[27], pl7);
     }
 #endif
     if (STATS) {
@@ -714,6 +727,8 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     P.block_stride = block_stride;
     P.n_local_rows = n_local_rows;
     P.tiles_x = (W + 7u) / 8u;
+    P.tiles_y = (n_local_rows + 7u) / 8u;
+    P.top_down = std::getenv("RTMI_TOPDOWN") ? 1u : 0u;
     const uint64_t n_work = (uint64_t)P.tiles_x * ((n_local_rows + 7u) / 8u) * 64u;
     if (n_work > 0xffffffffull) {
         set_error("rtmi: image too large for one launch");
@@ -835,6 +850,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
         h_mats[2 * i + 1] = make_uint4(fbits(m.p[3]), 0u, 0u, 0u);
     }
 
+    if (const char* e = std::getenv("RTMI_BLOCK")) s->block = (uint32_t)std::min(1024, std::max(64, (std::atoi(e) / 64) * 64));
     // LDS carve-up.  Small scenes live in LDS entirely (two workgroups per CU must fit: 80 KiB each); larger ones
     // stay in HBM and only the traversal stack is in LDS.
     auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };

@@ -11,28 +11,28 @@ def make(width, spp, depth, env, accel=None, stats=False):
     cam = pkg.camera_setup(pkg.camera_params(image_width=width, samples_per_pixel=spp, max_depth=depth))
     objs, mats = pkg.make_world_spheres(12345)
     sc = pkg.Scene(cam, objs, mats, accel=accel or pkg.ACCEL_BVH, collect_stats=stats)
-    for k in env:
-        os.environ.pop(k, None)
-    return sc, cam
+    return sc, cam, env
 
 if __name__ == "__main__":
     w = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    variants = {"v1": dict(RTMI_WAIT_THRESH=64)}
-    for th in (24, 32, 40, 48, 56):
-        variants[f"w{th}"] = dict(RTMI_WAIT_THRESH=th)
+    variants = {"w56": dict(RTMI_WAIT_THRESH=56), "old56": dict(RTMI_WAIT_THRESH=56, RTMI_FLAGS=2), "w60": dict(RTMI_WAIT_THRESH=60), "old60": dict(RTMI_WAIT_THRESH=60, RTMI_FLAGS=2)}
     scenes = {k: make(w, spp, 50, v) for k, v in variants.items()}
     ref = None
     res = {k: [] for k in scenes}
     for rnd in range(3):
-        for k, (sc, cam) in scenes.items():
+        for k, (sc, cam, env) in scenes.items():
+            for kk, vv in env.items():
+                os.environ[kk] = str(vv)
             rgb, _ = sc.render_rows(0, cam.img_height, 7)
+            for kk in env:
+                os.environ.pop(kk, None)
             res[k].append(sc.last_kernel_ms())
             if ref is None:
                 ref = rgb
             elif rnd == 0:
                 d = int((rgb.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())
                 print(f"{k}: pixels differing from v1: {d}", flush=True)
-    n = scenes["v1"][1].img_width * scenes["v1"][1].img_height * spp
+    n = scenes["w56"][1].img_width * scenes["w56"][1].img_height * spp
     for k, v in res.items():
         print(f"{k:10s} kernel ms min {min(v):8.2f} med {sorted(v)[len(v)//2]:8.2f}  -> {n/min(v)/1e3:8.1f} Msamples/s", flush=True)
