@@ -64,3 +64,38 @@ def random_spheres(n, seed=1, extent=10.0):
             p = (float(rng.uniform(1.2, 1.7)), 0.0, 0.0, 0.0)
         spec.append((c, r, (k, p)))
     return arrays(spec)
+
+
+def big_grid(n_side=316, seed=4):
+    """BASELINE config 4 shape: n_side^2 spheres (R = 0.2) on a jittered unit grid over a ground sphere, RTOW material
+    mix (80 % Lambertian, 15 % Metal, 5 % Dielectric); returns (objs, mats, camera kwargs)."""
+    rng = np.random.default_rng(seed)
+    n = n_side * n_side
+    objs = np.zeros(n + 1, OBJECT_DTYPE)
+    mats = np.zeros(n + 1, MATERIAL_DTYPE)
+    half = n_side / 2.0
+    objs[0] = (0, (0.0, -10000.0, 0.0), 10000.0, 0)
+    mats[0] = (0, (0.5, 0.5, 0.5, 0.0))
+    gx, gz = np.meshgrid(np.arange(n_side), np.arange(n_side), indexing="ij")
+    cx = (gx.ravel() - half + 0.9 * rng.random(n)).astype(np.float32)
+    cz = (gz.ravel() - half + 0.9 * rng.random(n)).astype(np.float32)
+    objs["center"][1:, 0] = cx
+    objs["center"][1:, 1] = 0.2
+    objs["center"][1:, 2] = cz
+    objs["radius"][1:] = 0.2
+    objs["material"][1:] = np.arange(1, n + 1)
+    choose = rng.random(n)
+    kind = np.where(choose < 0.8, 0, np.where(choose < 0.95, 1, 2)).astype(np.uint32)
+    mats["kind"][1:] = kind
+    p = np.zeros((n, 4), np.float32)
+    lam, met, die = kind == 0, kind == 1, kind == 2
+    p[lam, :3] = (rng.random((lam.sum(), 3)) * rng.random((lam.sum(), 3))).astype(np.float32)
+    p[met, :3] = rng.uniform(0.5, 1.0, (met.sum(), 3)).astype(np.float32)
+    p[met, 3] = rng.uniform(0.0, 0.5, met.sum()).astype(np.float32)
+    p[die, 0] = rng.uniform(1.2, 1.6, die.sum()).astype(np.float32)
+    mats["p"][1:] = p
+    scale = n_side / 22.0
+    cam = dict(aspect_ratio=16.0 / 9.0, image_width=1920, samples_per_pixel=256, max_depth=50, vertical_fov=20.0,
+               defocus_angle=0.6, focus_distance=10.0 * scale, lookfrom=(13.0 * scale, 2.0 * scale, 3.0 * scale),
+               lookat=(0.0, 0.0, 0.0), world_up=(0.0, 1.0, 0.0))
+    return objs, mats, cam

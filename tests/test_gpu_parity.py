@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 from tests.conftest import GOLDEN
-from tests.scenes import arrays, cornell_like, random_spheres, three_spheres, three_spheres_camera
+from tests.scenes import arrays, big_grid, cornell_like, random_spheres, three_spheres, three_spheres_camera
 
 pytestmark = pytest.mark.gpu
 
@@ -309,3 +309,44 @@ def test_config3_full_frame_sharding_invariance(pkg, rtow, gpu):
         frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev))
         assert torch.equal(frame.view(torch.int32), full.view(torch.int32))
         assert torch.isfinite(full).all() and 0.2 < float(full.mean()) < 0.8
+
+
+def test_config4_100k_spheres(pkg, ob, gpu):
+    """config 4: 100k spheres with a full BVH (2.4 MB of spheres + 6.4 MB of nodes stay in HBM).  The BVH walk, the
+    linear scan on the GPU and the oracle's linear scan agree bit for bit."""
+    objs, mats, kw = big_grid(316)
+    assert len(objs) > 99000
+    kw.update(image_width=96, samples_per_pixel=2)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as s:
+        rgb, rgba = s.render_rows(0, cam.img_height, 31)
+        again, _ = s.render_rows(0, cam.img_height, 31)
+    assert again.tobytes() == rgb.tobytes()
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BRUTE) as s:
+        brute, brute8 = s.render_rows(0, cam.img_height, 31)
+    _assert_frames_equal(rgb, brute)
+    assert np.array_equal(rgba, brute8)
+    rng = np.random.default_rng(5)
+    for x, y in zip(rng.integers(0, cam.img_width, 16), rng.integers(0, cam.img_height, 16)):
+        want, _ = ob.render_rect_counter(ocam, objs, mats, 31, int(x), int(y), int(x) + 1, int(y) + 1)
+        assert want[0, 0].tobytes() == rgb[y, x].tobytes()
+
+
+def test_config5_cornell_full_resolution(pkg, ob, gpu):
+    """config 5 shape at full resolution (800x800, 200 bounces; spp cut to 8 to keep the test short): deep-bounce
+    paths through both accel paths, and an oracle spot check."""
+    objs, mats, kw = cornell_like()
+    kw.update(samples_per_pixel=8)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    assert (cam.img_width, cam.img_height, cam.maxdepth) == (800, 800, 200)
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, collect_stats=True) as s:
+        rgb, _ = s.render_rows(0, 800, 9)
+        st = s.stats()
+    assert st["segments"] / st["samples"] > 20  # deep paths indeed
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BRUTE) as s:
+        brute, _ = s.render_rows(0, 800, 9)
+    _assert_frames_equal(rgb, brute)
+    rng = np.random.default_rng(6)
+    for x, y in zip(rng.integers(0, 800, 16), rng.integers(0, 800, 16)):
+        want, _ = ob.render_rect_counter(ocam, objs, mats, 9, int(x), int(y), int(x) + 1, int(y) + 1)
+        assert want[0, 0].tobytes() == rgb[y, x].tobytes()

@@ -16,7 +16,10 @@ def make(width, spp, depth, env, accel=None, stats=False):
 if __name__ == "__main__":
     w = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    variants = {"w56": dict(RTMI_WAIT_THRESH=56), "old56": dict(RTMI_WAIT_THRESH=56, RTMI_FLAGS=2), "w60": dict(RTMI_WAIT_THRESH=60), "old60": dict(RTMI_WAIT_THRESH=60, RTMI_FLAGS=2)}
+    variants = {"w56": dict(RTMI_WAIT_THRESH=56, RTMI_LAM_THRESH=99)}
+    for lt in (8, 16, 24, 32):
+        for wt in (40, 56):
+            variants[f"l{lt}w{wt}"] = dict(RTMI_WAIT_THRESH=wt, RTMI_LAM_THRESH=lt)
     scenes = {k: make(w, spp, 50, v) for k, v in variants.items()}
     ref = None
     res = {k: [] for k in scenes}
