@@ -157,7 +157,9 @@ int rtmi_render_rows(rtmi_scene* scene, uint32_t y0, uint32_t y1, uint64_t seed,
 /* Same, row-block sharded and device-resident (multi-GPU path): renders `n_blocks` blocks of `block_rows` rows,
  * block k covering rows [y_first + k*block_stride*block_rows, +block_rows) clipped to the image, into a dense
  * slice of n_blocks*block_rows rows.  Outputs are DEVICE pointers (either may be NULL); the launch is
- * asynchronous on `hip_stream` (a hipStream_t, NULL = default stream). */
+ * asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).  Launches on one scene share its work
+ * counter and sample buffer: issue them on ONE stream (or wait for the previous one) -- use one scene per stream
+ * for concurrent frames. */
 int rtmi_render_row_blocks_device(rtmi_scene* scene, uint32_t y_first, uint32_t block_rows, uint32_t block_stride,
                                   uint32_t n_blocks, uint64_t seed, void* d_rgb_linear_out, void* d_rgba8_out,
                                   void* hip_stream);
@@ -178,8 +180,9 @@ int rtmi_scene_get_bvh(const rtmi_scene* scene, rtmi_bvh_node* nodes_out, uint32
 int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, rtmi_bvh_node* nodes_out,
                    uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref, uint32_t* depth,
                    float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor);
-/* duration in milliseconds of the most recent kernel launch of this scene, from HIP events recorded on the launch
- * stream (blocks until that launch has finished); used by bench.py for the roofline line */
+/* duration in milliseconds of the most recent TRACE kernel of this scene (the ordered resolve pass that follows it is
+ * not included), from HIP events recorded on the launch stream; blocks until that launch has finished.  Used by
+ * bench.py for the roofline line. */
 int rtmi_scene_last_kernel_ms(rtmi_scene* scene, float* ms_out);
 
 #ifdef __cplusplus

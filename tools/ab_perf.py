@@ -16,10 +16,9 @@ def make(width, spp, depth, env, accel=None, stats=False):
 if __name__ == "__main__":
     w = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    variants = {"w56": dict(RTMI_WAIT_THRESH=56, RTMI_LAM_THRESH=99)}
-    for lt in (8, 16, 24, 32):
-        for wt in (40, 56):
-            variants[f"l{lt}w{wt}"] = dict(RTMI_WAIT_THRESH=wt, RTMI_LAM_THRESH=lt)
+    variants = {"w56": dict(RTMI_WAIT_THRESH=56)}
+    for wt in (32, 40, 48, 52, 60, 64):
+        variants[f"w{wt}"] = dict(RTMI_WAIT_THRESH=wt)
     scenes = {k: make(w, spp, 50, v) for k, v in variants.items()}
     ref = None
     res = {k: [] for k in scenes}
