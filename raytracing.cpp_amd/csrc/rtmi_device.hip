@@ -60,16 +60,16 @@ struct RtmiLaunch {
     uint32_t tiles_x, tiles_y, n_work; // work index space = tiles * 64
     uint32_t top_down;
     // sample-chunk split: a work item is `chunk` consecutive samples of one pixel; their colours go to sample_buf
-    // ([pixel][sample][3] floats) and rtmi_resolve_kernel adds them up in sample order.  n_chunks == 1: a lane owns
+    // ([pixel][sample] float4) and rtmi_resolve_kernel adds them up in sample order.  n_chunks == 1: a lane owns
     // the whole pixel and sums in registers.
     uint32_t chunk, n_chunks;
-    float* sample_buf;
+    float4* sample_buf;
     uint32_t wait_thresh;     // leave the traversal loop when this many lanes of a wave wait for shading
     uint64_t seed;
     float* out_rgb;
     uint32_t* out_rgba;
     uint32_t* work_counter;
-    uint32_t* att_stack; // [maxdepth][total_lanes] material handles of the non-dielectric bounces of the live path
+    uint32_t* att_stack; // [lane][maxdepth] {handle, count}: attenuation runs that did not fit LDS
     unsigned long long* stats; // {samples, segments, sphere_tests, node_tests}
 };
 
@@ -169,7 +169,7 @@ DEV V3 random_unit_vector(Rng& r, uint64_t seed) {
 // lane state machine
 // ---------------------------------------------------------------------------------------------------------
 enum : uint32_t { PH_FETCH = 0, PH_GEN = 1, PH_TRAV = 2, PH_SHADE = 3, PH_DONE = 4 };
-constexpr uint32_t kAttLds = 8; // attenuation handles kept in LDS per lane; deeper ones go to a per-lane L2-resident strip
+constexpr uint32_t kAttLds = 8; // closed attenuation runs kept in LDS per lane; more material changes spill to HBM
 
 struct Trav { // per-segment traversal state
     V3 o, d;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
     StackT* lds_stack = reinterpret_cast<StackT*>(lds_raw + P.lds_stack);
-    uint16_t* lds_att = reinterpret_cast<uint16_t*>(lds_raw + P.lds_att);
+    uint32_t* lds_att = reinterpret_cast<uint32_t*>(lds_raw + P.lds_att);
     const uint4* lds_spheres;
     const uint4* lds_aux;
     const uint4* lds_mats;
@@ -264,18 +264,35 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0;
     PF_DECL
 
-    // attenuation chain: material handles of the non-dielectric bounces of the live path.  The first kAttLds live in
-    // LDS; deeper ones (paths trapped inside the ground sphere run to maxdepth) in a per-lane contiguous strip that
-    // stays L2-resident, so the chain costs no HBM traffic.
+    // attenuation chain: material handles of the non-dielectric bounces of the live path, run-length encoded (a path
+    // trapped inside the ground sphere bounces 50 times on the same material: one run).  The open run lives in two
+    // registers, closed runs in LDS (kAttLds per lane, {handle, count} packed in 32 bits); only a path with more than
+    // kAttLds material changes spills to a per-lane strip in HBM.  rocprofv3 on the un-encoded chain: 90 GB of
+    // write-backs per 1080p x 512 spp frame, all of it this strip.
     const uint32_t maxdepth = P.cam.maxdepth;
-    auto att_push = [&](uint32_t h) {
-        if (!BIG && natt < kAttLds) lds_att[natt * blockDim.x + threadIdx.x] = (uint16_t)h;
-        else P.att_stack[(size_t)glane * maxdepth + natt] = h;
-        natt++;
+    uint32_t run_h = 0, run_n = 0;
+    auto att_store = [&](uint32_t q, uint32_t h, uint32_t n) {
+        if (!BIG && q < kAttLds) {
+            lds_att[q * blockDim.x + threadIdx.x] = h | (n << 16);
+        } else {
+            P.att_stack[((size_t)glane * maxdepth + q) * 2u] = h;
+            P.att_stack[((size_t)glane * maxdepth + q) * 2u + 1u] = n;
+        }
     };
-    auto att_get = [&](uint32_t q) -> uint32_t {
-        if (!BIG && q < kAttLds) return lds_att[q * blockDim.x + threadIdx.x];
-        return P.att_stack[(size_t)glane * maxdepth + q];
+    auto att_push = [&](uint32_t h) {
+        if (run_n != 0u && h == run_h) {
+            run_n++;
+        } else {
+            if (run_n != 0u) att_store(natt++, run_h, run_n);
+            run_h = h;
+            run_n = 1u;
+        }
+    };
+    auto att_apply = [&](V3 color, uint32_t h, uint32_t n) -> V3 {
+        const uint4 m0 = lds_mats[2u * h];
+        const V3 a = mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w));
+        for (uint32_t c = 0; c < n; ++c) color = vmul(a, color); // A*(A*(...)): one multiply per bounce, in order
+        return color;
     };
     auto begin_segment = [&](V3 o, V3 d) {
         t.o = o;
@@ -362,6 +379,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
             }
             depth_left = P.cam.maxdepth;
             natt = 0;
+            run_n = 0;
             if (depth_left == 0) {
                 // compute_color(depth == 0) returns 0 at once (core.cc:238-240): the sample is black
                 t.cur = 0xfffffffeu; // marker read by SHADE: finish the sample without tracing
@@ -555,9 +573,18 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                 const V3 unit_dir = vnormalize(t.d);
                 const float tt = 0.5f * (unit_dir.y + 1.0f);
                 color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
+                color = att_apply(color, run_h, run_n);
                 for (uint32_t q = natt; q-- > 0u;) {
-                    const uint4 m0 = lds_mats[2u * att_get(q)];
-                    color = vmul(mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w)), color);
+                    uint32_t h, n;
+                    if (!BIG && q < kAttLds) {
+                        const uint32_t e = lds_att[q * blockDim.x + threadIdx.x];
+                        h = e & 0xffffu;
+                        n = e >> 16;
+                    } else {
+                        h = P.att_stack[((size_t)glane * maxdepth + q) * 2u];
+                        n = P.att_stack[((size_t)glane * maxdepth + q) * 2u + 1u];
+                    }
+                    color = att_apply(color, h, n);
                 }
                 ended = true;
                 PF_MARK(pf7);
@@ -565,11 +592,8 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
             PF_MARK(pf8);
             if (ended) {
                 // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
-                if (P.sample_buf) {
-                    float* dst = P.sample_buf + ((size_t)((size_t)ply * W + px) * spp + s) * 3u;
-                    dst[0] = color.x;
-                    dst[1] = color.y;
-                    dst[2] = color.z;
+                if (P.sample_buf) { // one 16-byte store per sample
+                    P.sample_buf[(size_t)((size_t)ply * W + px) * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
                 } else {
                     sum = vadd(sum, color);
                 }
@@ -622,14 +646,25 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
 
 // Ordered resolve of the sample-chunk split: pixel_color += sample, s = 0 .. spp-1, exactly the sequential fp32 sum of
 // raytrace_pixel (core.cc:260-263), then * pixels_sample_scale and RGBAColor (core.cc:264, color.hpp:30-36).
-__global__ void __launch_bounds__(256) rtmi_resolve_kernel(const float* __restrict__ sample_buf, uint32_t n_pixels,
+__global__ void __launch_bounds__(256) rtmi_resolve_kernel(const float4* __restrict__ sample_buf, uint32_t n_pixels,
                                                            uint32_t spp, float scale, float* __restrict__ out_rgb,
                                                            uint32_t* __restrict__ out_rgba) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
-    const float* src = sample_buf + (size_t)p * spp * 3u;
+    const float4* src = sample_buf + (size_t)p * spp;
     V3 sum = mk(0.0f, 0.0f, 0.0f);
-    for (uint32_t k = 0; k < spp; ++k) sum = vadd(sum, mk(src[3u * k], src[3u * k + 1u], src[3u * k + 2u]));
+    uint32_t k = 0;
+    for (; k + 4u <= spp; k += 4u) { // a whole 64-byte line per lane and trip
+        const float4 c0 = src[k], c1 = src[k + 1u], c2 = src[k + 2u], c3 = src[k + 3u];
+        sum = vadd(sum, mk(c0.x, c0.y, c0.z));
+        sum = vadd(sum, mk(c1.x, c1.y, c1.z));
+        sum = vadd(sum, mk(c2.x, c2.y, c2.z));
+        sum = vadd(sum, mk(c3.x, c3.y, c3.z));
+    }
+    for (; k < spp; ++k) {
+        const float4 c = src[k];
+        sum = vadd(sum, mk(c.x, c.y, c.z));
+    }
     const V3 outc = vscale(sum, scale);
     if (out_rgb) {
         out_rgb[3u * p + 0u] = outc.x;
@@ -677,8 +712,8 @@ struct rtmi_scene {
     float* d_rgb = nullptr;     // staging for rtmi_render_rows (host-pointer entry)
     uint32_t* d_rgba = nullptr; // staging
     size_t staging_pixels = 0;
-    float* d_samples = nullptr; // sample-chunk split: [pixel][sample][3]
-    size_t samples_capacity = 0; // floats
+    float4* d_samples = nullptr; // sample-chunk split: [pixel][sample]
+    size_t samples_capacity = 0; // records
     uint32_t chunk = ~0u;        // samples per work item of the split; ~0u: chosen per launch, 0: split off
     size_t sample_buf_cap_bytes = (size_t)24 << 30; // above this the split is off and a lane owns a whole pixel
     hipEvent_t ev2 = nullptr;    // end of the trace kernel (ev1 = end of the launch, resolve included)
@@ -780,12 +815,12 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     P.top_down = std::getenv("RTMI_TOPDOWN") ? 1u : 0u;
     // sample-chunk split: the cost of a pixel is heavy-tailed (paths trapped in the ground sphere run 50 bounces), so a
     // launch whose work items are whole pixels ends in a long tail (29 % of a 1080p x 512 spp frame, measured); items
-    // of `chunk` samples cut it by spp / chunk at the price of 12 B per sample written once and read once.
+    // of `chunk` samples cut it by spp / chunk at the price of 16 B per sample written once and read once.
     const uint32_t spp = s->cam.samples_per_pixel;
     P.chunk = spp;
     P.n_chunks = 1;
     P.sample_buf = nullptr;
-    const size_t sample_floats = (size_t)n_local_rows * W * spp * 3u;
+    const size_t sample_floats = (size_t)n_local_rows * W * spp; // float4 records
     // chunk size: aim at ~64 work items per lane of the persistent grid (A/B on MI355X at 1080p x 512 spp: 64-sample
     // chunks 422 ms, 32: 430, 128: 433, 16: 489, whole pixels 554), never below 16 samples
     uint32_t chunk = s->chunk;
@@ -795,12 +830,12 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
         const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, (want_items + pixels - 1) / pixels);
         chunk = std::max(16u, (spp + n_chunks - 1u) / std::max(1u, n_chunks));
     }
-    if (chunk && spp > chunk && sample_floats * sizeof(float) <= s->sample_buf_cap_bytes) {
+    if (chunk && spp > chunk && sample_floats * sizeof(float4) <= s->sample_buf_cap_bytes) {
         if (sample_floats > s->samples_capacity) {
             hipFree(s->d_samples);
             s->d_samples = nullptr;
             s->samples_capacity = 0;
-            if (hipMalloc(reinterpret_cast<void**>(&s->d_samples), sample_floats * sizeof(float)) == hipSuccess) {
+            if (hipMalloc(reinterpret_cast<void**>(&s->d_samples), sample_floats * sizeof(float4)) == hipSuccess) {
                 s->samples_capacity = sample_floats;
             } else {
                 (void)hipGetLastError(); // not enough HBM for the split: fall back to whole-pixel work items
@@ -947,7 +982,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) : 0u;
     const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 32u;
     const uint64_t small_total = scene_bytes + (uint64_t)s->stack_depth * s->block * 2u + 64u;
-    s->big = small_total + kAttLds * s->block * 2u > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u ||
+    s->big = small_total + kAttLds * s->block * 4u > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u ||
              n_objects > 0x2000u || n_materials > 0x10000u;
     if (const char* e = std::getenv("RTMI_FORCE_BIG")) s->big = s->big || std::atoi(e) != 0;
     uint32_t off = 0;
@@ -966,7 +1001,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     off += s->stack_depth * s->block * (s->big ? 4u : 2u);
     off = align16(off);
     s->lds_att = off;
-    if (!s->big) off += kAttLds * s->block * 2u;
+    if (!s->big) off += kAttLds * s->block * 4u;
     s->lds_bytes = align16(off);
     if (s->lds_bytes > 160u * 1024u) {
         set_error("rtmi_scene_create: traversal stack does not fit the 160 KiB LDS of a CU (BVH too deep)");
@@ -1005,7 +1040,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_counter), 16));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 32 * sizeof(unsigned long long)));
     HIP_TRY_S(hipMemset(s->d_stats, 0, 32 * sizeof(unsigned long long)));
-    const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * s->grid * s->block * sizeof(uint32_t));
+    const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * s->grid * s->block * 2u * sizeof(uint32_t));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_att), att_bytes));
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY_S(hipEventCreate(&s->ev0));
