@@ -140,6 +140,27 @@ def test_hbm_resident_scene_variant(pkg, ob, rtow, gpu, monkeypatch):
         assert np.array_equal(rgba, want8)
 
 
+def test_scheduling_knobs_do_not_change_the_image(pkg, ob, rtow, gpu, monkeypatch):
+    """Sample-chunk work items, the deferred-path queue (also when it overflows), launch geometry and the traversal
+    exit threshold are scheduling decisions: every combination yields the oracle's frame bit for bit."""
+    kw = dict(image_width=128, samples_per_pixel=96, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    want, want8 = ob.render_rect_counter(ocam, *rtow, 44, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
+    for env in (dict(RTMI_CHUNK="0"), dict(RTMI_CHUNK="16", RTMI_DEFER="0"), dict(RTMI_CHUNK="16", RTMI_DEFER="1"),
+                dict(RTMI_CHUNK="32", RTMI_DEFER_CAP="64"), dict(RTMI_CHUNK="40", RTMI_BLOCK="256", RTMI_WAIT_THRESH="20"),
+                dict(RTMI_BLOCKS_PER_CU="1", RTMI_WAIT_THRESH="64", RTMI_TOPDOWN="1")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True) as s:
+            rgb, rgba = s.render_rows(0, cam.img_height, 44)
+            st = s.stats()
+        for k in env:
+            monkeypatch.delenv(k)
+        _assert_frames_equal(rgb, want)
+        assert np.array_equal(rgba, want8)
+        assert st["samples"] == cam.img_width * cam.img_height * 96, env
+
+
 def test_degenerate_scenes(pkg, ob, gpu):
     kw = dict(image_width=40, samples_per_pixel=2, max_depth=5)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
