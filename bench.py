@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--accel", choices=("bvh", "brute"), default="bvh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline renders every n-th pixel in x and y")
+    ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline renders every n-th pixel in x and y")
     args = ap.parse_args()
 
     import numpy as np
@@ -205,8 +205,10 @@ def main():
             "flops_per_sample": round(fps, 1),
             "counters_per_sample": {k: round(ctr[k] / ctr["samples"], 3) for k in ctr if k != "samples"},
             "counters_source": f"oracle instrumented walk, {ctr['samples']} samples on a uniform pixel subset",
+            # scene staged once per workgroup-resident CU + 16-byte sample records written once (the ordered resolve
+            # pass reads them back) + framebuffer slice; the path is VALU-bound, HBM is reported as a sanity check
             "hbm_algorithmic_bytes_per_launch": int(len(objs) * (16 + 16 + 32) + (0 if bvh is None else len(bvh["nodes"]) * 64)
-                                                    + W * (H // world) * 16),
+                                                    + samples_per_launch * 16 + W * (H // world) * 16),
             "note": "fp32 VALU-bound path (SURVEY 8d): peak = non-FMA issue rate 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
         }
         # ---- CPU baseline: the oracle, reference-shaped job system, on this host's cores -----------------------
