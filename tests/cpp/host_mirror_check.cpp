@@ -1,11 +1,15 @@
 // Exercises the C++ host mirror (raytracing.cpp_amd/host/rtmi_host.hpp) the way the reference's own host would:
 //   host_mirror_check setup  <world.config.json> <seed>            -> dumps camera + scene records (no GPU needed)
 //   host_mirror_check render <world.config.json> <seed> <rseed> <out.bin>  -> default_setup + raytrace_rows on the GPU
+//   host_mirror_check display <surface_w> <surface_h> <img_w> <img_h> <out.bin>  -> write_pixel mapping (no GPU needed)
+//   host_mirror_check stream <world.config.json> <seed> <rseed> <surface_w> <surface_h> <out.bin> <out.ppm>
+//                            -> RayTracer (job-system adapter) streaming row blocks into the display contract on the GPU
 #include <cstdio>
 #include <cstring>
 #include <string>
 
 #include "rtmi_host.hpp"
+#include "rtmi_raytracer.hpp"
 
 using namespace rtmi;
 
@@ -18,6 +22,17 @@ static void dump(const void* p, size_t n) {
 int main(int argc, char** argv) {
     if (argc < 4) return 2;
     const std::string mode = argv[1];
+    if (mode == "display" && argc >= 7) {
+        const uint32_t sw = std::atoi(argv[2]), sh = std::atoi(argv[3]), iw = std::atoi(argv[4]), ih = std::atoi(argv[5]);
+        RayTracedImageTarget target(sw, sh, iw, ih);
+        for (uint32_t y = 0; y < ih; ++y)
+            for (uint32_t x = 0; x < iw; ++x) target.write_pixel(x, y, RGBAColor{0xff000000u | (y << 12) | x});
+        FILE* f = std::fopen(argv[6], "wb");
+        if (!f) return 8;
+        std::fwrite(target.ssbo(), 1, sizeof(RayTracedImageSSBOData) - sizeof(RGBAColor) + size_t(sw) * sh * sizeof(RGBAColor), f);
+        std::fclose(f);
+        return 0;
+    }
     try {
         const WorldDefinition wd = load_world_definition(argv[2]);
         const uint32_t seed = static_cast<uint32_t>(std::strtoul(argv[3], nullptr, 10));
@@ -62,6 +77,39 @@ int main(int argc, char** argv) {
             std::fwrite(rgb.data(), sizeof(float), rgb.size(), f);
             std::fwrite(rgba.data(), sizeof(RGBAColor), rgba.size(), f);
             std::fclose(f);
+            return 0;
+        }
+        if (mode == "stream" && argc >= 9) {
+            auto core = RayTracingCore::setup(wd, seed);
+            const uint64_t rseed = std::strtoull(argv[4], nullptr, 10);
+            const uint32_t sw = std::atoi(argv[5]), sh = std::atoi(argv[6]);
+            RayTracedImageTarget target(sw, sh, core->rts_img_width, core->rts_img_height);
+            auto tracer = RayTracer::create(core, rseed, 8, 2);
+            if (!tracer) return 3;
+            uint32_t last = 0, progress_steps = 0, frames = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (tracer->pixels_raytraced() < tracer->pixels_count()) { // the render_event delegate, main.cc:880
+                tracer->update(&target);
+                if (tracer->pixels_raytraced() != last) {
+                    ++progress_steps; // the UI's progress bar would move here (main.cc:378-388)
+                    last = tracer->pixels_raytraced();
+                }
+                ++frames;
+                if (tracer->worker_failed()) return 4;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return 5;
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            tracer->shutdown();
+            if (progress_steps < 3) return 6; // the image must arrive progressively, not in one piece
+            if (!(tracer->render_time().count() > 0.0)) return 7;
+            std::vector<RGBAColor> frame(size_t(core->rts_img_width) * core->rts_img_height);
+            if (core->raytrace_rows(0, core->rts_img_height, rseed, frame.data()) != RTMI_OK) return 4;
+            if (!write_ppm(argv[8], core->rts_img_width, core->rts_img_height, frame.data())) return 8;
+            FILE* f = std::fopen(argv[7], "wb");
+            if (!f) return 8;
+            std::fwrite(target.ssbo(), 1, sizeof(RayTracedImageSSBOData) - sizeof(RGBAColor) + size_t(sw) * sh * sizeof(RGBAColor), f);
+            std::fclose(f);
+            std::printf("frames %u progress_steps %u render_time %.4f\n", frames, progress_steps, tracer->render_time().count());
             return 0;
         }
     } catch (const std::exception& e) {

@@ -42,7 +42,7 @@ def exe(pkg, tmp_path_factory):
     out = str(tmp_path_factory.mktemp("cpp") / "host_mirror_check")
     libdir = os.path.dirname(pkg.LIB_PATH)
     subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
-                    "-I", os.path.join(libdir, "host"), CPP, "-o", out, "-L", libdir, "-lrtmi",
+                    "-I", os.path.join(libdir, "host"), CPP, "-o", out, "-L", libdir, "-lrtmi", "-lpthread",
                     f"-Wl,-rpath,{libdir}"], check=True)
     return out
 
@@ -106,3 +106,47 @@ def test_default_setup_and_render_through_the_mirror(exe, ob, tmp_path):
     objs, mats = ob.make_world_spheres(12345, ob.world_def(), _fixed_from_json())
     want, want8 = ob.render_rect_counter(ocam, objs, mats, 77, 0, 0, 96, ocam.img_height, nthreads=8)
     assert rgb.tobytes() == want.tobytes() and np.array_equal(rgba, want8)
+
+
+def _ssbo(path):
+    raw = open(path, "rb").read()
+    sw, sh = np.frombuffer(raw[:8], np.uint32)
+    # RayTracedImageSSBOData is alignas(16): {width, height, pad, pad?}: the pixel array starts at offset 8
+    pix = np.frombuffer(raw[8:8 + int(sw) * int(sh) * 4], np.uint32).reshape(sh, sw)
+    return int(sw), int(sh), pix
+
+
+def test_display_contract_centres_and_flips(exe, tmp_path):
+    """RayTracedImageDisplay::write_pixel (image.display.cc:108-117): image centred on the surface, GL lower-left origin."""
+    out = str(tmp_path / "ssbo.bin")
+    sw, sh, iw, ih = 40, 30, 24, 10
+    subprocess.run([exe, "display", str(sw), str(sh), str(iw), str(ih), out], check=True)
+    gw, gh, pix = _ssbo(out)
+    assert (gw, gh) == (sw, sh)
+    tx, ty = (sw - iw) // 2, (sh - ih) // 2
+    want = np.zeros((sh, sw), np.uint32)
+    for y in range(ih):
+        for x in range(iw):
+            want[sh - 1 - (y + ty), x + tx] = 0xff000000 | (y << 12) | x
+    assert np.array_equal(pix, want)
+
+
+@pytest.mark.gpu
+def test_job_system_adapter_streams_row_blocks_into_the_display(exe, ob, tmp_path):
+    cfg = str(tmp_path / "world.config.json")
+    _world_json(cfg, _camera(160, 4, 20))
+    out, ppm = str(tmp_path / "ssbo.bin"), str(tmp_path / "frame.ppm")
+    r = subprocess.run([exe, "stream", cfg, "12345", "5", "200", "120", out, ppm], check=True, capture_output=True,
+                       text=True)
+    assert "progress_steps" in r.stdout
+    ocam = ob.camera_setup(ob.camera_params(image_width=160, samples_per_pixel=4, max_depth=20))
+    objs, mats = ob.make_world_spheres(12345, ob.world_def(), _fixed_from_json())
+    _, want8 = ob.render_rect_counter(ocam, objs, mats, 5, 0, 0, 160, ocam.img_height, nthreads=8)
+    sw, sh, pix = _ssbo(out)
+    tx, ty = (200 - 160) // 2, (120 - ocam.img_height) // 2
+    img = pix[::-1][ty:ty + ocam.img_height, tx:tx + 160]  # undo the y-flip and the centring
+    assert np.array_equal(img, want8)
+    hdr, body = open(ppm, "rb").read().split(b"\n255\n", 1)
+    assert hdr == b"P6\n160 90"
+    rgb = np.frombuffer(body, np.uint8).reshape(90, 160, 3)
+    assert np.array_equal(rgb[..., 0], (want8 & 0xff).astype(np.uint8)) and np.array_equal(rgb[..., 2], ((want8 >> 16) & 0xff).astype(np.uint8))
