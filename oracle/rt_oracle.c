@@ -172,7 +172,11 @@ static inline v3 random_vector_range(orc_rng* r, double rmin, double rmax) {
  * against a double below the smallest float denormal, i.e. `> 0`. */
 static inline v3 random_unit_vector(orc_rng* r) {
     for (;;) {
+        /* counter stream only (build-side): every attempt takes one whole Philox block -- it starts at a block
+         * boundary and skips the fourth word -- so that any GPU lane can evaluate any attempt of any stream */
+        if (r->kind == ORC_RNG_COUNTER) r->k = (r->k + 3u) & ~3u;
         const v3 p = random_vector_range(r, -1.0, 1.0);
+        if (r->kind == ORC_RNG_COUNTER) r->k = (r->k + 3u) & ~3u;
         const float length_squared = vdot(p, p);
         if ((double)length_squared > 1e-160 && length_squared <= 1.0f) {
             return vdivs(p, sqrtf(length_squared));

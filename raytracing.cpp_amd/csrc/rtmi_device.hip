@@ -165,13 +165,74 @@ DEV float draw_pm1(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 4.65
 // random_unit_vector, random.number.gen.hpp:21-29 (`> 1e-160` on a float is `> 0`)
 DEV V3 random_unit_vector(Rng& r, uint64_t seed) {
     for (;;) {
+        r.k = (r.k + 3u) & ~3u; // every attempt takes one whole Philox block (see coop_unit_vector)
         const float x = draw_pm1(rng_u32(r, seed));
         const float y = draw_pm1(rng_u32(r, seed));
         const float z = draw_pm1(rng_u32(r, seed));
         const V3 p = mk(x, y, z);
         const float l2 = vdot(p, p);
+        r.k = (r.k + 3u) & ~3u;
         if (l2 > 0.0f && l2 <= 1.0f) return vdivs(p, __builtin_sqrtf(l2));
     }
+}
+
+// Cooperative form of the same loop, called by ALL lanes of a wave.  A rejection loop costs the wave its longest run
+// of rejections (6.6 passes for 1.9 attempts per lane at 52 % acceptance).  The draws are counter based, so any lane
+// can evaluate any attempt of any other lane's stream: every attempt takes one whole Philox block (it starts at a
+// block boundary and skips the fourth word), and each pass spreads the lanes still without a vector over all 64
+// lanes -- pass 1: one attempt each; pass 2: two attempts for each of the ~27 lanes left; pass 3: ~10 each.
+// `tbl` is 64 bytes of LDS private to the wave.  Returns the vector (unused where !need).
+DEV V3 coop_unit_vector(bool need, Rng& rng, uint64_t seed, volatile uint8_t* tbl) {
+    V3 out = mk(0.0f, 0.0f, 0.0f);
+    if (need) rng.k = (rng.k + 3u) & ~3u; // attempts are block aligned
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint64_t todo = __ballot(need);
+    bool pending = need;
+    while (todo != 0ull) {
+        const uint32_t n = (uint32_t)__popcll(todo);
+        const uint32_t per = min(64u / n, 8u); // attempts per pending lane in this pass
+        const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+        if (pending) tbl[my_rank] = (uint8_t)lane; // rank -> lane of the pending stream
+        // this lane evaluates attempt `a` of the pending lane of rank `r`
+        const uint32_t a = (uint32_t)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)n));
+        const uint32_t r = lane - a * n;
+        const bool helper = a < per;
+        const uint32_t src = tbl[r];
+        const uint32_t pix = (uint32_t)__shfl((int)rng.pixel, (int)src);
+        const uint32_t smp = (uint32_t)__shfl((int)rng.sample, (int)src);
+        const uint32_t kb = (uint32_t)__shfl((int)rng.k, (int)src);
+        bool ok = false;
+        V3 u = mk(0.0f, 0.0f, 0.0f);
+        if (helper) {
+            Rng tmp;
+            philox4x32_10((kb >> 2) + a, smp, pix, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), tmp);
+            const V3 q = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
+            const float l2 = vdot(q, q);
+            if (l2 > 0.0f && l2 <= 1.0f) { // random.number.gen.hpp:25-27
+                ok = true;
+                u = vdivs(q, __builtin_sqrtf(l2));
+            }
+        }
+        const uint64_t okm = __ballot(ok);
+        // the pending lane takes its first accepted attempt, in attempt order
+        uint32_t first = per;
+#pragma unroll
+        for (uint32_t c = 8u; c-- > 0u;) {
+            if (c < per && ((okm >> (my_rank + c * n)) & 1ull)) first = c;
+        }
+        const bool found = pending && first < per;
+        const uint32_t from = found ? my_rank + first * n : lane;
+        const float ux = __shfl(u.x, (int)from), uy = __shfl(u.y, (int)from), uz = __shfl(u.z, (int)from);
+        if (found) {
+            out = mk(ux, uy, uz);
+            rng.k += 4u * (first + 1u);
+            pending = false;
+        } else if (pending) {
+            rng.k += 4u * per;
+        }
+        todo = __ballot(pending);
+    }
+    return out;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -233,7 +294,8 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     // per-wave pools: work indices and deferred-path slots are taken from the global counters 64 at a time (a single
     // counter word saturates at ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M
     // work items and 35 M deferred paths)
-    uint32_t* pool = reinterpret_cast<uint32_t*>(lds_raw + P.lds_pool) + (threadIdx.x >> 6) * 4u;
+    uint32_t* pool = reinterpret_cast<uint32_t*>(lds_raw + P.lds_pool) + (threadIdx.x >> 6) * 20u;
+    volatile uint8_t* rank_tbl = reinterpret_cast<volatile uint8_t*>(pool + 4); // 64 bytes, see coop_unit_vector
     if ((threadIdx.x & 63u) == 0u) {
         pool[0] = 0u; pool[1] = 0u; pool[2] = 0u; pool[3] = 0u;
     }
@@ -555,6 +617,10 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
         PF_LANES(pl4, __ballot(phase == PH_SHADE && t.best == ~0u));
         PF_LANES(pl7, __ballot(phase == PH_DONE));
         // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
+        // unit vectors for every Lambertian / Metallic hit of this round, generated by the whole wave together
+        bool need_unit = false;
+        if (phase == PH_SHADE && t.cur != 0xfffffffeu && t.best != ~0u) need_unit = lds_mats[2u * lds_aux[t.best].y].x != 2u;
+        const V3 unit_vec = coop_unit_vector(need_unit, rng, P.seed, rank_tbl);
         if (phase == PH_SHADE) {
             bool ended = false;
             V3 color = mk(0.0f, 0.0f, 0.0f);
@@ -582,7 +648,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                     // random_unit_vector(): the wave pays the longest run of rejections once, not once per material.
                     V3 rn = mk(0.0f, 0.0f, 0.0f);
                     if (kind == 1u) rn = vnormalize(vreflect(t.d, N));
-                    const V3 u = random_unit_vector(rng, P.seed);
+                    const V3 u = unit_vec; // random_unit_vector(), random.number.gen.hpp:21-29
                     if (kind == 0u) {
                         sd = vadd(N, u);
                         const float eps = 1e-8f; // near_zero, ray.tracer.math.hpp:16-19
@@ -1140,7 +1206,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     s->lds_att = off;
     if (!s->big) off += kAttLds * s->block * 4u;
     s->lds_pool = off; // per wave: {work_next, work_end, slot_next, slot_end}
-    off += (s->block / 64u) * 16u;
+    off += (s->block / 64u) * 80u; // + 64-byte rank table of coop_unit_vector
     s->lds_bytes = align16(off);
     if (s->lds_bytes > 160u * 1024u) {
         set_error("rtmi_scene_create: traversal stack does not fit the 160 KiB LDS of a CU (BVH too deep)");
