@@ -85,6 +85,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RTMI_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = 0  # rehearsal: every rank on the one visible GPU
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -93,7 +95,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") over xGMI is the product path; RTMI_DIST_BACKEND=gloo lets two ranks share ONE GPU for a
+        # rehearsal of everything but the collective itself (RCCL refuses two ranks on one device)
+        backend = os.environ.get("RTMI_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cp = pkg.camera_params(image_width=args.width, samples_per_pixel=args.spp, max_depth=args.depth)
     cam = pkg.camera_setup(cp)
@@ -113,6 +121,10 @@ def main():
         if n_blocks:
             scene.render_row_blocks_device(y_first, BLOCK_ROWS, world, n_blocks, RENDER_SEED, rgb.data_ptr(),
                                            rgba.data_ptr(), stream)
+        if world > 1 and dist.get_backend() != "nccl":  # rehearsal backend: stage through host memory
+            torch.cuda.synchronize(dev)
+            f, f8 = pkg.gather_frame(rgb.cpu(), plan, rank), pkg.gather_frame(rgba.cpu(), plan, rank)
+            return (f.to(dev), f8.to(dev)) if rank == 0 else (None, None)
         frame = pkg.gather_frame(rgb, plan, rank)
         frame8 = pkg.gather_frame(rgba, plan, rank)
         return frame, frame8
