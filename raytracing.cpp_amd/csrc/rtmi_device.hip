@@ -349,6 +349,8 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     // write-backs per 1080p x 512 spp frame, all of it this strip.
     const uint32_t maxdepth = P.cam.maxdepth;
     uint32_t run_h = 0, run_n = 0;
+    V3 pend0 = mk(0.0f, 0.0f, 0.0f), pend1 = pend0, pend2 = pend0; // finished samples waiting for their 64-byte line
+    uint32_t npend = 0;
     auto att_store = [&](uint32_t q, uint32_t h, uint32_t n) {
         if (!BIG && q < kAttLds) {
             lds_att[q * blockDim.x + threadIdx.x] = h | (n << 16);
@@ -724,7 +726,15 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                             }
                         }
                         if (deferred) {
-                            // the drain launch will store (and count) this sample; move on to the next one
+                            // the drain launch will store (and count) this sample; write out the finished ones that
+                            // were waiting for it and move on to the next one
+                            if (npend > 0u) {
+                                float4* dst = P.sample_buf + (size_t)((size_t)ply * W + px) * spp + (s - npend);
+                                dst[0] = make_float4(pend0.x, pend0.y, pend0.z, 0.0f);
+                                if (npend > 1u) dst[1] = make_float4(pend1.x, pend1.y, pend1.z, 0.0f);
+                                if (npend > 2u) dst[2] = make_float4(pend2.x, pend2.y, pend2.z, 0.0f);
+                                npend = 0u;
+                            }
                             s++;
                             phase = (s >= s_end) ? PH_FETCH : PH_GEN;
                         } else {
@@ -757,8 +767,24 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
             PF_MARK(pf8);
             if (ended) {
                 // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
-                if (P.sample_buf) { // one 16-byte store per sample
-                    P.sample_buf[(size_t)((size_t)ply * W + px) * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
+                if (P.sample_buf) {
+                    // 16-byte sample records, written a 64-byte line at a time: up to three finished samples wait in
+                    // registers until the fourth of their line (or the end of the chunk) arrives, so that the four
+                    // stores hit L2 back to back and leave it as one full line (a lone 16-byte store costs ~43 bytes
+                    // of write-back at the fabric, measured)
+                    if ((s & 3u) == 3u || s + 1u >= s_end) {
+                        float4* dst = P.sample_buf + (size_t)((size_t)ply * W + px) * spp + (s - npend);
+                        if (npend > 0u) dst[0] = make_float4(pend0.x, pend0.y, pend0.z, 0.0f);
+                        if (npend > 1u) dst[1] = make_float4(pend1.x, pend1.y, pend1.z, 0.0f);
+                        if (npend > 2u) dst[2] = make_float4(pend2.x, pend2.y, pend2.z, 0.0f);
+                        dst[npend] = make_float4(color.x, color.y, color.z, 0.0f);
+                        npend = 0u;
+                    } else {
+                        if (npend == 0u) pend0 = color;
+                        else if (npend == 1u) pend1 = color;
+                        else pend2 = color;
+                        npend++;
+                    }
                 } else {
                     sum = vadd(sum, color);
                 }
