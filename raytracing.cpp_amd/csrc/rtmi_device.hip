@@ -519,7 +519,9 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
             // Two kinds of step: an internal node (two slab tests) or a leaf (its spheres).  Each iteration the wave
             // runs only the kind that holds more of its traversing lanes; the other lanes keep their place.
             for (;;) {
-                const bool at_leaf = (t.cur & kLeafBit) != 0u;
+                // LDS-resident scenes carry their node/leaf references in the 16-bit form of the stack entries
+                // (0x8000 | (count-1) << 13 | first slot for a leaf): no packing or unpacking on push / pop
+                const bool at_leaf = (t.cur & (BIG ? kLeafBit : 0x8000u)) != 0u;
                 const uint64_t m_node = __ballot(phase == PH_TRAV && !at_leaf);
                 const uint64_t m_leaf = __ballot(phase == PH_TRAV && at_leaf);
                 if ((m_node | m_leaf) == 0ull) break;
@@ -532,7 +534,8 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                 bool pop = false;
                 if (n_leaf > n_node) {
                     if (phase == PH_TRAV && at_leaf) {
-                        const uint32_t first = t.cur & 0x00ffffffu, cnt = (t.cur >> 24) & 0x7fu;
+                        const uint32_t first = BIG ? (t.cur & 0x00ffffffu) : (t.cur & 0x1fffu);
+                        const uint32_t cnt = BIG ? ((t.cur >> 24) & 0x7fu) : (((t.cur >> 13) & 3u) + 1u);
                         for (uint32_t q = 0; q < cnt; ++q) {
                             const uint4 raw = lds_spheres[first + q];
                             const float4 sph = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y),
@@ -568,16 +571,13 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                     if (STATS) st_node += 2;
                     const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
                     const uint32_t ch0 = n3.x, ch1 = n3.y;
+                    asm volatile("" ::"v"(ch0), "v"(ch1)); // keep the child-reference read with the box reads (one LDS round trip)
                     if (hit0 || hit1) {
                         const bool both = hit0 && hit1;
                         const bool take1 = both ? (tn1 < tn0) : hit1;
                         if (both) {
                             const uint32_t far_ref = take1 ? ch0 : ch1;
-                            // 16-bit stack entry: node index, or leaf as 0x8000 | (count-1) << 13 | first slot
-                            const uint32_t packed = BIG ? far_ref : ((far_ref & kLeafBit)
-                                ? (0x8000u | ((((far_ref >> 24) & 0x7fu) - 1u) << 13) | (far_ref & 0x1fffu))
-                                : far_ref);
-                            lds_stack[t.sp * blockDim.x + threadIdx.x] = (StackT)packed;
+                            lds_stack[t.sp * blockDim.x + threadIdx.x] = (StackT)far_ref;
                             t.sp++;
                         }
                         t.cur = take1 ? ch1 : ch0;
@@ -590,10 +590,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                         phase = PH_SHADE;
                     } else {
                         t.sp--;
-                        const uint32_t packed = lds_stack[t.sp * blockDim.x + threadIdx.x];
-                        t.cur = BIG ? packed : ((packed & 0x8000u)
-                            ? (kLeafBit | ((((packed >> 13) & 3u) + 1u) << 24) | (packed & 0x1fffu))
-                            : packed);
+                        t.cur = lds_stack[t.sp * blockDim.x + threadIdx.x];
                     }
                 }
             }
@@ -921,6 +918,7 @@ struct rtmi_scene {
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
     uint32_t wait_thresh = 56; // lanes waiting for shading that end a traversal round (A/B on MI355X: 56 best)
     uint32_t lds_att = 0, lds_pool = 0;
+    uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     hipStream_t stream = nullptr; // private stream of the blocking entry point
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -994,7 +992,7 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     P.n_slots = s->n_objects;
     P.n_mats = s->n_mats;
     P.n_nodes = (uint32_t)s->bvh.nodes.size();
-    P.root_ref = s->bvh.root_ref;
+    P.root_ref = s->root_ref_dev;
     std::memcpy(P.pad_classes, s->bvh.pad_classes, sizeof(P.pad_classes));
     P.n_pad_classes = s->bvh.n_pad_classes;
     P.pad_eps = s->bvh.pad_eps;
@@ -1248,7 +1246,22 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     HIP_TRY_S(upload(&s->d_spheres, h_spheres.data(), h_spheres.size() * sizeof(uint4)));
     HIP_TRY_S(upload(&s->d_aux, h_aux.data(), h_aux.size() * sizeof(uint4)));
     HIP_TRY_S(upload(&s->d_mats, h_mats.data(), h_mats.size() * sizeof(uint4)));
-    HIP_TRY_S(upload(&s->d_nodes, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(rtmi_bvh_node)));
+    {
+        // device copy of the nodes: LDS-resident scenes get their references in the 16-bit stack-entry form
+        std::vector<rtmi_bvh_node> dn = s->bvh.nodes;
+        auto pack16 = [](uint32_t ref) {
+            return (ref & kLeafBit) ? (0x8000u | ((((ref >> 24) & 0x7fu) - 1u) << 13) | (ref & 0x1fffu)) : ref;
+        };
+        s->root_ref_dev = s->bvh.root_ref;
+        if (!s->big && s->accel == RTMI_ACCEL_BVH && n_objects > 0) {
+            for (auto& nd : dn) {
+                nd.child[0] = pack16(nd.child[0]);
+                nd.child[1] = pack16(nd.child[1]);
+            }
+            s->root_ref_dev = pack16(s->bvh.root_ref);
+        }
+        HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
+    }
 
     // persistent grid: exactly as many workgroups as the device keeps resident
     KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big);
