@@ -49,7 +49,7 @@ struct RtmiLaunch {
     const uint4* aux;      // [n_slots] {object index, material handle, radius bits, 0}
     const uint4* mats;     // [n_mats]  2 x uint4 per material: {kind, p0, p1, p2}, {p3, 0, 0, 0}
     const uint4* nodes;    // [n_nodes] 4 x uint4 per node (rtmi_bvh_node)
-    uint32_t n_slots, n_mats, n_nodes, root_ref;
+    uint32_t n_slots, n_mats, n_nodes, root_ref, n_top_nodes;
     float pad_classes[kMaxPadClasses][8];
     uint32_t n_pad_classes;
     float pad_eps, pad_floor;
@@ -303,11 +303,18 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     const uint4* lds_aux;
     const uint4* lds_mats;
     const uint4* lds_nodes;
+    const uint4* top_nodes = nullptr; // BIG: the first n_top_nodes nodes (breadth-first numbering) staged into LDS
     if (BIG) {
         lds_spheres = P.spheres;
         lds_aux = P.aux;
         lds_mats = P.mats;
         lds_nodes = P.nodes;
+        if (ACCEL == RTMI_ACCEL_BVH && P.n_top_nodes) {
+            uint4* w_top = reinterpret_cast<uint4*>(lds_raw + P.lds_nodes);
+            for (uint32_t i = threadIdx.x; i < 4u * P.n_top_nodes; i += blockDim.x) w_top[i] = P.nodes[i];
+            __syncthreads();
+            top_nodes = w_top;
+        }
     } else {
         // ---- stage the scene into LDS: coalesced 16-byte loads, one pass per array -------------------------
         uint4* w_spheres = reinterpret_cast<uint4*>(lds_raw + P.lds_spheres);
@@ -546,10 +553,12 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                         pop = true;
                     }
                 } else if (phase == PH_TRAV && !at_leaf) {
-                    const uint4 n0 = lds_nodes[4u * t.cur + 0u];
-                    const uint4 n1 = lds_nodes[4u * t.cur + 1u];
-                    const uint4 n2 = lds_nodes[4u * t.cur + 2u];
-                    const uint4 n3 = lds_nodes[4u * t.cur + 3u];
+                    // config 4: the top levels of the tree are in LDS, the rest is read from L2 / Infinity Cache
+                    const uint4* np = (BIG && t.cur < P.n_top_nodes) ? top_nodes + 4u * t.cur : lds_nodes + 4u * t.cur;
+                    const uint4 n0 = np[0];
+                    const uint4 n1 = np[1];
+                    const uint4 n2 = np[2];
+                    const uint4 n3 = np[3];
                     // rtmi_bvh_node: ctr[2][3] | half[2][3] | child[2] | reserved[2]
                     const float c0x = __uint_as_float(n0.x), c0y = __uint_as_float(n0.y), c0z = __uint_as_float(n0.z);
                     const float c1x = __uint_as_float(n0.w), c1y = __uint_as_float(n1.x), c1z = __uint_as_float(n1.y);
@@ -919,6 +928,7 @@ struct rtmi_scene {
     uint32_t wait_thresh = 56; // lanes waiting for shading that end a traversal round (A/B on MI355X: 56 best)
     uint32_t lds_att = 0, lds_pool = 0;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
+    uint32_t n_top_nodes = 0;  // HBM-resident scenes: nodes staged into LDS (top of the breadth-first numbered tree)
     hipStream_t stream = nullptr; // private stream of the blocking entry point
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -993,6 +1003,7 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     P.n_mats = s->n_mats;
     P.n_nodes = (uint32_t)s->bvh.nodes.size();
     P.root_ref = s->root_ref_dev;
+    P.n_top_nodes = s->n_top_nodes;
     std::memcpy(P.pad_classes, s->bvh.pad_classes, sizeof(P.pad_classes));
     P.n_pad_classes = s->bvh.n_pad_classes;
     P.pad_eps = s->bvh.pad_eps;
@@ -1223,6 +1234,15 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
         s->lds_mats = off;
         off += n_materials * 32u;
         off = align16(off);
+    }
+    if (s->big && s->accel == RTMI_ACCEL_BVH) {
+        // two workgroups per CU: 80 KiB each; what the stack, the pools and the chain leave goes to the top of the tree
+        const uint32_t fixed = s->stack_depth * s->block * 4u + (s->block / 64u) * 80u + 256u;
+        const uint32_t budget = fixed < 72u * 1024u ? 72u * 1024u - fixed : 0u;
+        s->n_top_nodes = (uint32_t)std::min<size_t>(s->bvh.nodes.size(), budget / 64u);
+        if (const char* e = std::getenv("RTMI_TOP_NODES")) s->n_top_nodes = (uint32_t)std::min<size_t>(s->bvh.nodes.size(), (size_t)std::max(0, std::atoi(e)));
+        s->lds_nodes = off;
+        off += s->n_top_nodes * 64u;
     }
     s->lds_stack = off;
     off += s->stack_depth * s->block * (s->big ? 4u : 2u);

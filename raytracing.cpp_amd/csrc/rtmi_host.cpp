@@ -438,6 +438,32 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
     out.nodes = std::move(b.nodes);
     out.slot_object = std::move(b.slots);
     out.depth = b.depth;
+    // Breadth-first numbering: the levels every ray walks through come first, so that the kernel variant for scenes
+    // that do not fit LDS can keep the top of the tree there (rtmi_device.hip, `top_nodes`).
+    if (!out.nodes.empty() && !(out.root_ref & kLeafBit)) {
+        const uint32_t nn = static_cast<uint32_t>(out.nodes.size());
+        std::vector<uint32_t> order;
+        order.reserve(nn);
+        std::vector<uint32_t> new_index(nn, 0u);
+        order.push_back(out.root_ref);
+        for (size_t head = 0; head < order.size(); ++head) {
+            const rtmi_bvh_node& nd = out.nodes[order[head]];
+            for (int k = 0; k < 2; ++k) {
+                if (!(nd.child[k] & kLeafBit)) order.push_back(nd.child[k]);
+            }
+        }
+        for (uint32_t i = 0; i < nn; ++i) new_index[order[i]] = i;
+        std::vector<rtmi_bvh_node> renum(nn);
+        for (uint32_t i = 0; i < nn; ++i) {
+            rtmi_bvh_node nd = out.nodes[order[i]];
+            for (int k = 0; k < 2; ++k) {
+                if (!(nd.child[k] & kLeafBit)) nd.child[k] = new_index[nd.child[k]];
+            }
+            renum[i] = nd;
+        }
+        out.nodes = std::move(renum);
+        out.root_ref = 0;
+    }
 
     // Per-ray pad: a sphere of radius R seen from distance L is accepted by the fp32 discriminant of
     // object.defs.cc:43-50 only if the ray passes within sqrt(R^2 + k*u*L^2) of its centre (u = 2^-24, k <= 15),
