@@ -285,7 +285,9 @@ DEV void sphere_test(const float4 sph, const Trav& t, uint32_t slot, uint32_t ob
 // BIG = false: the whole scene is staged into LDS and stack entries are packed into 16 bits (<= 8192 spheres).
 // BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
 //              32-bit entries (config 4: 100k spheres, 2.4 MB of spheres + 6.4 MB of nodes).
-template <int ACCEL, bool STATS, bool BIG>
+// DRAIN = true: the launch that finishes the deferred paths (work items are queue records; no primary rays, no
+// chunk bookkeeping, no further deferral) -- same arithmetic, leaner control flow.
+template <int ACCEL, bool STATS, bool BIG, bool DRAIN>
 __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
@@ -432,7 +434,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
             take = __shfl(take, leader);
             if (rank >= take) continue; // pool ran dry mid-request: ask again
             const uint32_t idx = start + rank;
-            if (P.mode == 1u) {
+            if (DRAIN) {
                 // drain launch: a work item is one deferred path; resume it exactly where the primary launch left it
                 if (idx >= min(*P.defer_count, P.defer_cap)) {
                     phase = PH_DONE;
@@ -483,7 +485,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
         PF_LANES(pl5, __ballot(phase == PH_GEN));
 
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
-        if (phase == PH_GEN) {
+        if (!DRAIN && phase == PH_GEN) {
             const uint32_t blk = ply / P.block_rows;
             const uint32_t gy = P.y_first + blk * P.block_stride * P.block_rows + (ply - blk * P.block_rows);
             rng.k = 0;
@@ -697,7 +699,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                         ended = true; // the next compute_color call returns 0 (core.cc:238-240)
                     } else {
                         bool deferred = false;
-                        if (!BIG && P.mode == 0u && P.defer_buf && !front && kind != 2u && natt <= 4u && depth_left >= 8u) {
+                        if (!DRAIN && !BIG && P.defer_buf && !front && kind != 2u && natt <= 4u && depth_left >= 8u) {
                             // wave-aggregated append to the deferred-path queue (ballot + prefix popcount)
                             const uint64_t m = __ballot(1);
                             const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -823,7 +825,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
         }
     }
 
-    if (P.mode == 0u && P.defer_buf && lane == 0u) { // reserved but unused slots become empty records (depth 0)
+    if (!DRAIN && P.defer_buf && lane == 0u) { // reserved but unused slots become empty records (depth 0)
         for (uint32_t q = pool[2]; q < pool[3]; ++q) {
             if (q < P.defer_cap) P.defer_buf[(size_t)q * 5u + 2u] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -927,6 +929,7 @@ struct rtmi_scene {
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
     uint32_t wait_thresh = 56; // lanes waiting for shading that end a traversal round (A/B on MI355X: 56 best)
     uint32_t lds_att = 0, lds_pool = 0;
+    uint32_t drain_wait_thresh = 56;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     uint32_t n_top_nodes = 0;  // HBM-resident scenes: nodes staged into LDS (top of the breadth-first numbered tree)
     hipStream_t stream = nullptr; // private stream of the blocking entry point
@@ -941,12 +944,17 @@ using KernelFn = void (*)(const RtmiLaunch);
 
 template <int ACCEL>
 KernelFn pick_variant(bool stats, bool big) {
-    if (big) return stats ? rtmi_trace_kernel<ACCEL, true, true> : rtmi_trace_kernel<ACCEL, false, true>;
-    return stats ? rtmi_trace_kernel<ACCEL, true, false> : rtmi_trace_kernel<ACCEL, false, false>;
+    if (big) return stats ? rtmi_trace_kernel<ACCEL, true, true, false> : rtmi_trace_kernel<ACCEL, false, true, false>;
+    return stats ? rtmi_trace_kernel<ACCEL, true, false, false> : rtmi_trace_kernel<ACCEL, false, false, false>;
 }
 
 KernelFn pick_kernel(uint32_t accel, bool stats, bool big) {
     return accel == RTMI_ACCEL_BVH ? pick_variant<RTMI_ACCEL_BVH>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE>(stats, big);
+}
+
+// the drain launch exists for LDS-resident BVH scenes only (that is where paths are deferred)
+KernelFn pick_drain_kernel(bool stats) {
+    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, false, true> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, false, true>;
 }
 
 void free_scene(rtmi_scene* s) {
@@ -1063,7 +1071,7 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     P.defer_count = s->d_counter + 2;
     P.defer_cap = 0;
     P.mode = 0;
-    if (P.sample_buf && s->defer_enabled && !s->big && s->cam.maxdepth >= 16) {
+    if (P.sample_buf && s->defer_enabled && !s->big && s->accel == RTMI_ACCEL_BVH && s->cam.maxdepth >= 16) {
         uint64_t want = std::min<uint64_t>((uint64_t)n_local_rows * W * spp / 16u + 65536u, 0x7fffffffull / 5u);
         if (const char* e = std::getenv("RTMI_DEFER_CAP")) want = (uint64_t)std::max(64, std::atoi(e)); // tests: force overflow
         if (want > s->defer_cap) {
@@ -1101,8 +1109,10 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
         RtmiLaunch D = P;
         D.mode = 1;
         D.work_counter = s->d_counter + 1;
+        D.wait_thresh = s->drain_wait_thresh;
         void* dargs[] = {&D};
-        HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), dargs, s->lds_bytes, stream));
+        HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(pick_drain_kernel(s->collect_stats)), dim3(s->grid),
+                                dim3(s->block), dargs, s->lds_bytes, stream));
     }
     HIP_TRY(hipEventRecord(s->ev2, stream));
     if (P.sample_buf) {
@@ -1176,6 +1186,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     s->n_objects = n_objects;
     s->n_mats = n_materials;
     s->accel = opt.accel == RTMI_ACCEL_AUTO ? (n_objects > 8 ? RTMI_ACCEL_BVH : RTMI_ACCEL_BRUTE) : opt.accel;
+    if (n_objects == 0) s->accel = RTMI_ACCEL_BRUTE; // an empty world has no tree; the scan over zero spheres misses
     if (s->accel != RTMI_ACCEL_BVH && s->accel != RTMI_ACCEL_BRUTE) {
         set_error("rtmi_scene_create: unknown accel");
         return fail(RTMI_ERR_BAD_ARG);
@@ -1287,6 +1298,10 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big);
     HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)s->lds_bytes));
+    if (!s->big && s->accel == RTMI_ACCEL_BVH) {
+        HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_drain_kernel(s->collect_stats)),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    }
     int per_cu = 0;
     HIP_TRY_S(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)s->block, s->lds_bytes));
     if (per_cu < 1) {
@@ -1299,6 +1314,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     if (const char* e = std::getenv("RTMI_WAIT_THRESH")) s->wait_thresh = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RTMI_CHUNK")) s->chunk = (uint32_t)std::max(0, std::atoi(e)); // 0: split off
     if (const char* e = std::getenv("RTMI_DEFER")) s->defer_enabled = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RTMI_DRAIN_WAIT")) s->drain_wait_thresh = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RTMI_SAMPLE_BUF_MB")) s->sample_buf_cap_bytes = (size_t)std::max(0, std::atoi(e)) << 20;
     s->grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
 

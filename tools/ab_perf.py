@@ -16,7 +16,9 @@ def make(width, spp, depth, env, accel=None, stats=False):
 if __name__ == "__main__":
     w = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    variants = {"w56": dict(), "b640": dict(RTMI_BLOCK=640), "b576": dict(RTMI_BLOCK=576), "b640w60": dict(RTMI_BLOCK=640, RTMI_WAIT_THRESH=60), "b448": dict(RTMI_BLOCK=448)}
+    variants = {"w56": dict()}
+    for wt in (40, 48, 60, 64):
+        variants[f"dw{wt}"] = dict(RTMI_DRAIN_WAIT=wt)
     scenes = {k: make(w, spp, 50, v) for k, v in variants.items()}
     ref = None
     res = {k: [] for k in scenes}
