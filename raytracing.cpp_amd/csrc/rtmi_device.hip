@@ -238,7 +238,7 @@ DEV V3 coop_unit_vector(bool need, Rng& rng, uint64_t seed, volatile uint8_t* tb
 // ---------------------------------------------------------------------------------------------------------
 // lane state machine
 // ---------------------------------------------------------------------------------------------------------
-enum : uint32_t { PH_FETCH = 0, PH_GEN = 1, PH_TRAV = 2, PH_SHADE = 3, PH_DONE = 4 };
+enum : uint32_t { PH_FETCH = 0, PH_GEN = 1, PH_TRAV = 2, PH_SHADE = 3, PH_DONE = 4, PH_BEGIN = 5 };
 constexpr uint32_t kAttLds = 8; // closed attenuation runs kept in LDS per lane; more material changes spill to HBM
 
 struct Trav { // per-segment traversal state
@@ -459,9 +459,9 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                     for (uint32_t q = 0; q < 4u; ++q) {
                         if (q < natt) lds_att[q * blockDim.x + threadIdx.x] = e[q];
                     }
-                    begin_segment(mk(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
-                                  mk(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)));
-                    phase = PH_TRAV;
+                    t.o = mk(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                    t.d = mk(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                    phase = PH_BEGIN;
                 }
             } else if (idx >= P.n_work) {
                 phase = PH_DONE;
@@ -517,9 +517,15 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                 t.best = ~0u;
                 phase = PH_SHADE;
             } else {
-                begin_segment(origin, vsub(pixel_sample, origin));
-                phase = PH_TRAV;
+                t.o = origin;
+                t.d = vsub(pixel_sample, origin);
+                phase = PH_BEGIN;
             }
+        }
+        // every new segment of this round -- primary rays, scattered rays, resumed paths -- is set up here, once
+        if (phase == PH_BEGIN) {
+            begin_segment(t.o, t.d);
+            phase = PH_TRAV;
         }
 
         PF_MARK(pf1);
@@ -746,8 +752,9 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                             s++;
                             phase = (s >= s_end) ? PH_FETCH : PH_GEN;
                         } else {
-                            begin_segment(p, sd);
-                            phase = PH_TRAV;
+                            t.o = p;
+                            t.d = sd;
+                            phase = PH_BEGIN; // set up before the next traversal, together with the new primary rays
                         }
                     }
                 }

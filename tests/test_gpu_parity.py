@@ -376,3 +376,24 @@ def test_config5_cornell_full_resolution(pkg, ob, gpu):
     for x, y in zip(rng.integers(0, 800, 16), rng.integers(0, 800, 16)):
         want, _ = ob.render_rect_counter(ocam, objs, mats, 9, int(x), int(y), int(x) + 1, int(y) + 1)
         _assert_frames_equal(rgb[y, x][None, None], want)
+
+
+@pytest.mark.parametrize("config", ["2", "3"])
+def test_full_frame_digest_matches_oracle(pkg, rtow, gpu, config):
+    """BASELINE configs 2 and 3, WHOLE frame against the oracle's linear scan: the oracle frames took minutes / an hour
+    on 8 CPU cores (tests/golden/make_full_frame_hashes.py), so their SHA-256 digests are the fixture.  Equal digests
+    mean every float of the frame is bit-identical (NaNs canonicalised)."""
+    import hashlib
+    path = os.path.join(GOLDEN, "full_frame_hashes.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    if config not in doc:
+        pytest.skip("no oracle digest committed for this config")
+    ref = doc[config]
+    cam = pkg.camera_setup(pkg.camera_params(**ref["camera"]))
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH) as s:
+        rgb, rgba = s.render_rows(0, cam.img_height, ref["render_seed"])
+    u = rgb.view(np.uint32).copy()
+    u[np.isnan(rgb)] = 0x7fc00000
+    assert int(np.isnan(rgb).any(axis=-1).sum()) == ref["nan_pixels"]
+    assert hashlib.sha256(np.ascontiguousarray(rgba).tobytes()).hexdigest() == ref["sha256_rgba8"]
+    assert hashlib.sha256(u.tobytes()).hexdigest() == ref["sha256_rgb_float32"]
