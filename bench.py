@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--accel", choices=("bvh", "brute"), default="bvh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-linear-scan", action="store_true", help="skip the extra linear-scan (reference algorithm) step")
     ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline renders every n-th pixel in x and y")
     args = ap.parse_args()
 
@@ -208,7 +209,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("width") == args.width and tj.get("spp") == args.spp and tj.get("n_gpus") == world:
+                if (tj.get("width") == args.width and tj.get("spp") == args.spp and tj.get("n_gpus") == world
+                        and args.accel == "bvh"):
                     traffic = tj.get("bytes_per_launch")
             except Exception:
                 traffic = None
@@ -225,6 +227,26 @@ def main():
                                                     + samples_per_launch * 16 + W * (H // world) * 16),
             "note": "fp32 VALU-bound path (SURVEY 8d): peak = non-FMA issue rate 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
         }
+        # ---- the reference's own algorithm on the GPU: linear closest-hit scan, same frame, one untimed-in-`value` step --
+        if world == 1 and args.accel == "bvh" and not args.no_linear_scan:
+            bvh_frame = frame.clone()  # `frame` is a view of `rgb` at world == 1
+            lin = pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BRUTE, device=local_rank)
+            lin.render_row_blocks_device(0, H, 1, 1, RENDER_SEED, rgb.data_ptr(), 0, stream)
+            torch.cuda.synchronize(dev)
+            lin.render_row_blocks_device(0, H, 1, 1, RENDER_SEED, rgb.data_ptr(), 0, stream)
+            torch.cuda.synchronize(dev)
+            lin_ms = lin.last_kernel_ms()
+            lin.close()
+            same = bool(torch.equal(torch.nan_to_num(rgb[:H]).view(torch.int32), torch.nan_to_num(bvh_frame).view(torch.int32)))
+            lin_fps = ctr["segments"] / ctr["samples"] * (len(objs) * 23.0 + 70.0)
+            out["linear_scan_kernel"] = {
+                "value": round(samples / lin_ms / 1e3, 2), "unit": "Msamples/s", "kernel_ms": round(lin_ms, 3),
+                "flops_per_sample": round(lin_fps, 1),
+                "roofline_frac": round(samples * lin_fps / (lin_ms / 1e3) / 1e12 / VALU_PEAK_TFLOPS, 4),
+                "frame_bit_identical_to_bvh": same,
+                "note": "rtmi_trace_kernel<brute>: the reference's O(N) scan (object.defs.cc:68-81), spheres in LDS; "
+                        "the BVH walk returns the same frame with ~17x less algorithmic work",
+            }
         # ---- CPU baseline: the oracle, reference-shaped job system, on this host's cores -----------------------
         if world == 1 and not args.no_cpu_baseline:
             hw = usable_cpus()
