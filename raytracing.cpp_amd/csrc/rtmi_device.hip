@@ -282,6 +282,24 @@ DEV void sphere_test(const float4 sph, const Trav& t, uint32_t slot, uint32_t ob
     }
 }
 
+// The two halves of the same test for the linear scan, which works on four spheres at a time: the discriminant
+// (cheap, every sphere, every lane) and the root (IEEE sqrt and divisions, only where delta >= 0: 0.4 % of the tests).
+DEV void sphere_delta(const uint4 raw, const Trav& t, float& h, float& delta) {
+    const V3 oc = mk(__uint_as_float(raw.x) - t.o.x, __uint_as_float(raw.y) - t.o.y, __uint_as_float(raw.z) - t.o.z);
+    h = vdot(t.d, oc);
+    const float c = vdot(oc, oc) - __uint_as_float(raw.w);
+    delta = h * h - t.a * c;
+}
+DEV void sphere_root(float h, float delta, const Trav& t, uint32_t slot, float& tbest, uint32_t& best) {
+    const float sqrtd = __builtin_sqrtf(delta);
+    float root = (h - sqrtd) / t.a;
+    if (!(root > 0.0001f)) root = (h + sqrtd) / t.a;
+    if (root > 0.0001f && root < tbest) { // strict <: the first inserted object wins a tie (object.defs.cc:73)
+        tbest = root;
+        best = slot;
+    }
+}
+
 // BIG = false: the whole scene is staged into LDS and stack entries are packed into 16 bits (<= 8192 spheres).
 // BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
 //              32-bit entries (config 4: 100k spheres, 2.4 MB of spheres + 6.4 MB of nodes).
@@ -616,12 +634,27 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
             // sphere, so every LDS read is a broadcast.
             if (__ballot(phase == PH_TRAV) != 0ull) {
                 if (phase == PH_TRAV) {
-                    for (uint32_t i = 0; i < P.n_slots; ++i) {
-                        const uint4 raw = lds_spheres[i];
-                        const float4 sph = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y),
-                                                       __uint_as_float(raw.z), __uint_as_float(raw.w));
-                        sphere_test(sph, t, i, i, true, lds_aux, t.tbest, t.best, t.bestobj);
+                    uint32_t i = 0;
+                    for (; i + 4u <= P.n_slots; i += 4u) { // four broadcast reads in flight, four discriminants, then the rare roots
+                        const uint4 r0 = lds_spheres[i], r1 = lds_spheres[i + 1u], r2 = lds_spheres[i + 2u], r3 = lds_spheres[i + 3u];
+                        float h0, h1, h2, h3, d0, d1, d2, d3;
+                        sphere_delta(r0, t, h0, d0);
+                        sphere_delta(r1, t, h1, d1);
+                        sphere_delta(r2, t, h2, d2);
+                        sphere_delta(r3, t, h3, d3);
+                        if (fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) { // insertion order, as the reference scans
+                            if (d0 >= 0.0f) sphere_root(h0, d0, t, i, t.tbest, t.best);
+                            if (d1 >= 0.0f) sphere_root(h1, d1, t, i + 1u, t.tbest, t.best);
+                            if (d2 >= 0.0f) sphere_root(h2, d2, t, i + 2u, t.tbest, t.best);
+                            if (d3 >= 0.0f) sphere_root(h3, d3, t, i + 3u, t.tbest, t.best);
+                        }
                     }
+                    for (; i < P.n_slots; ++i) {
+                        float h0, d0;
+                        sphere_delta(lds_spheres[i], t, h0, d0);
+                        if (d0 >= 0.0f) sphere_root(h0, d0, t, i, t.tbest, t.best);
+                    }
+                    t.bestobj = t.best;
                     if (STATS) st_sphere += P.n_slots;
                     phase = PH_SHADE;
                 }
