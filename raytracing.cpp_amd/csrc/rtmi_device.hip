@@ -246,7 +246,6 @@ struct Trav { // per-segment traversal state
     float a;          // dot(d, d), object.defs.cc:44
     float tbest;      // closest accepted root so far (Interval::Max, object.defs.cc:69)
     uint32_t best;    // slot of the closest sphere, ~0u = none
-    uint32_t bestobj; // its object index (tie rule: first inserted wins, object.defs.cc:73)
     uint32_t cur;     // BVH: current node/leaf reference; brute force: unused
     uint32_t sp;      // BVH: stack entries
     V3 inv, oinv, pinv; // BVH slab test: 1/d, -o/d, pad*|1/d|
@@ -254,36 +253,11 @@ struct Trav { // per-segment traversal state
 
 DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// HittableObject_Sphere::intersects candidate root (object.defs.cc:41-60): root1 if it is beyond tmin, else root2.
-// Acceptance against the shrinking Max is done by the caller.  sph = {C, R*R}.
-DEV void sphere_test(const float4 sph, const Trav& t, uint32_t slot, uint32_t obj_or_slot, bool slot_is_obj,
-                     const uint4* lds_aux, float& tbest, uint32_t& best, uint32_t& bestobj) {
-    const V3 oc = mk(sph.x - t.o.x, sph.y - t.o.y, sph.z - t.o.z);
-    const float h = vdot(t.d, oc);
-    const float c = vdot(oc, oc) - sph.w;
-    const float delta = h * h - t.a * c;
-    if (delta >= 0.0f) {
-        const float sqrtd = __builtin_sqrtf(delta);
-        float root = (h - sqrtd) / t.a;
-        if (!(root > 0.0001f)) root = (h + sqrtd) / t.a; // Interval{0.0001, .}.surrounds, interval.hpp:14
-        if (root > 0.0001f) {
-            if (root < tbest) {
-                tbest = root;
-                best = slot;
-                bestobj = slot_is_obj ? obj_or_slot : lds_aux[slot].x;
-            } else if (!slot_is_obj && root == tbest) {
-                const uint32_t obj = lds_aux[slot].x;
-                if (obj < bestobj) {
-                    best = slot;
-                    bestobj = obj;
-                }
-            }
-        }
-    }
-}
-
-// The two halves of the same test for the linear scan, which works on four spheres at a time: the discriminant
-// (cheap, every sphere, every lane) and the root (IEEE sqrt and divisions, only where delta >= 0: 0.4 % of the tests).
+// HittableObject_Sphere::intersects (object.defs.cc:41-60) in two halves.  The candidate root of a sphere does not
+// depend on the shrinking Max (root1 if it is beyond tmin, else root2); acceptance against Max is done by the caller.
+// Spheres are stored as {C, R*R}.
+// The discriminant (cheap, every sphere, every lane) and the root (IEEE sqrt and divisions, only where delta >= 0:
+// 0.4 % of the tests of the linear scan, which works on four spheres at a time).
 DEV void sphere_delta(const uint4 raw, const Trav& t, float& h, float& delta) {
     const V3 oc = mk(__uint_as_float(raw.x) - t.o.x, __uint_as_float(raw.y) - t.o.y, __uint_as_float(raw.z) - t.o.z);
     h = vdot(t.d, oc);
@@ -297,6 +271,22 @@ DEV void sphere_root(float h, float delta, const Trav& t, uint32_t slot, float& 
     if (root > 0.0001f && root < tbest) { // strict <: the first inserted object wins a tie (object.defs.cc:73)
         tbest = root;
         best = slot;
+    }
+}
+
+// Root + acceptance for the BVH walk, where leaves are not visited in insertion order: a strictly closer root wins; an
+// exactly equal one wins only if its object was inserted earlier (what the reference's in-order scan with `<` yields).
+DEV void sphere_root_bvh(float h, float delta, const Trav& t, uint32_t slot, const uint4* aux, float& tbest, uint32_t& best) {
+    const float sqrtd = __builtin_sqrtf(delta);
+    float root = (h - sqrtd) / t.a;
+    if (!(root > 0.0001f)) root = (h + sqrtd) / t.a;
+    if (root > 0.0001f) {
+        if (root < tbest) {
+            tbest = root;
+            best = slot;
+        } else if (root == tbest && best != ~0u) {
+            if (aux[slot].x < aux[best].x) best = slot;
+        }
     }
 }
 
@@ -407,7 +397,6 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
         t.a = vdot(d, d);
         t.tbest = __builtin_inff();
         t.best = ~0u;
-        t.bestobj = ~0u;
         t.sp = 0;
         if (ACCEL == RTMI_ACCEL_BVH) {
             t.cur = P.root_ref;
@@ -569,11 +558,15 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                     if (phase == PH_TRAV && at_leaf) {
                         const uint32_t first = BIG ? (t.cur & 0x00ffffffu) : (t.cur & 0x1fffu);
                         const uint32_t cnt = BIG ? ((t.cur >> 24) & 0x7fu) : (((t.cur >> 13) & 3u) + 1u);
-                        for (uint32_t q = 0; q < cnt; ++q) {
-                            const uint4 raw = lds_spheres[first + q];
-                            const float4 sph = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y),
-                                                           __uint_as_float(raw.z), __uint_as_float(raw.w));
-                            sphere_test(sph, t, first + q, 0u, false, lds_aux, t.tbest, t.best, t.bestobj);
+                        for (uint32_t q = 0; q < cnt; q += 2u) { // two spheres per trip: both discriminants, then the roots
+                            const bool two = q + 1u < cnt;
+                            const uint4 r0 = lds_spheres[first + q];
+                            const uint4 r1 = lds_spheres[first + (two ? q + 1u : q)];
+                            float h0, h1, d0, d1;
+                            sphere_delta(r0, t, h0, d0);
+                            sphere_delta(r1, t, h1, d1);
+                            if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, first + q, lds_aux, t.tbest, t.best);
+                            if (two && d1 >= 0.0f) sphere_root_bvh(h1, d1, t, first + q + 1u, lds_aux, t.tbest, t.best);
                         }
                         if (STATS) st_sphere += cnt;
                         pop = true;
@@ -654,7 +647,6 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                         sphere_delta(lds_spheres[i], t, h0, d0);
                         if (d0 >= 0.0f) sphere_root(h0, d0, t, i, t.tbest, t.best);
                     }
-                    t.bestobj = t.best;
                     if (STATS) st_sphere += P.n_slots;
                     phase = PH_SHADE;
                 }
