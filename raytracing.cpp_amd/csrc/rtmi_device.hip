@@ -9,16 +9,20 @@
 //   RGBAColor(vec3), linear_to_gamma, clamp                       src/color.hpp:9-36, src/ray.tracer.math.hpp:10-19
 //
 // Design (MI355X-first):
-//  * persistent lanes: every lane owns one pixel at a time and walks its samples in order (the reference's
-//    sequential fp32 sum, core.cc:260-263); finished lanes pull the next pixel of an 8x8-tiled index space from a
-//    global counter with one wave-aggregated atomic (ballot + prefix popcount).
-//  * recursion flattened: a lane is a small state machine FETCH -> GEN -> TRAVERSE -> SHADE; the attenuation chain
-//    A1*(A2*(...*sky)) of the recursive compute_color is replayed innermost-first at path end from a per-lane
-//    stack of material handles, so the colour is bit-identical to the recursion.
-//  * the wave leaves the traversal loop as soon as enough lanes wait for shading (ballot/popcount), shades them,
-//    refills them with their next ray and re-enters traversal: lanes never idle through a whole bounce.
+//  * persistent lanes: a work item is a chunk of consecutive samples of one pixel; lanes take items from per-wave
+//    pools refilled 64 at a time from a global counter (ballot + prefix popcount), store one 16-byte record per
+//    sample, and rtmi_resolve_kernel adds the records up in sample order (the reference's sequential fp32 sum,
+//    core.cc:260-263).
+//  * recursion flattened: a lane is a small state machine FETCH -> GEN -> BEGIN -> TRAVERSE -> SHADE; the attenuation
+//    chain A1*(A2*(...*sky)) of the recursive compute_color is replayed innermost-first at path end from run-length
+//    encoded material handles kept in LDS, so the colour is bit-identical to the recursion.
+//  * traversal: per iteration the wave votes between a node step and a leaf step; it leaves the loop as soon as
+//    enough lanes wait for shading (ballot/popcount), shades them, refills them and re-enters traversal.
+//  * rejection sampling of random_unit_vector is done by the whole wave together (coop_unit_vector).
+//  * paths that turn out to bounce inside an opaque sphere are deferred to a compacted queue and finished by a
+//    second launch (DRAIN variant) whose lanes all walk such paths.
 //  * scene (BVH nodes, spheres, materials) staged once per workgroup into LDS with coalesced 16-byte loads; the
-//    per-lane traversal stack lives in LDS too.
+//    per-lane traversal stack lives in LDS too.  Scenes that do not fit stay in HBM (BIG variant), top of the tree in LDS.
 //  * counter RNG: Philox4x32-10 keyed by seed, counter (draw block, sample, pixel): the image does not depend on
 //    tiling, row sharding or GPU count.
 //  * arithmetic of the reference path is kept operation for operation (no FMA contraction, IEEE sqrt/div); only the
