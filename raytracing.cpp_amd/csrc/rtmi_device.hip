@@ -134,12 +134,14 @@ DEV V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 // random_double() = u32 * 2^-32.  The affine maps of random.number.gen.hpp are exact in double for a 32-bit
 // draw, so the double -> float narrowing of the reference equals one int -> float conversion here.
 // ---------------------------------------------------------------------------------------------------------
-struct Rng {
+struct Rng { // per-lane stream position; no cached block: every consumer asks for the block it needs
     uint32_t k, pixel, sample;
+};
+struct Blk {
     uint32_t w0, w1, w2, w3;
 };
 
-DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, Rng& r) {
+DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, Blk& r) {
 #pragma unroll
     for (int round = 0; round < 10; ++round) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -155,32 +157,24 @@ DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     r.w0 = c0; r.w1 = c1; r.w2 = c2; r.w3 = c3;
 }
 
-DEV uint32_t rng_u32(Rng& r, uint64_t seed) {
+DEV Blk rng_block(const Rng& r, uint32_t blk, uint64_t seed) {
+    Blk b;
+    philox4x32_10(blk, r.sample, r.pixel, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), b);
+    return b;
+}
+DEV uint32_t rng_u32(Rng& r, uint64_t seed) { // one draw at the current position
     const uint32_t k = r.k++;
+    const Blk b = rng_block(r, k >> 2, seed);
     const uint32_t j = k & 3u;
-    if (j == 0u) philox4x32_10(k >> 2, r.sample, r.pixel, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    return j == 0u ? r.w0 : (j == 1u ? r.w1 : (j == 2u ? r.w2 : r.w3));
+    return j == 0u ? b.w0 : (j == 1u ? b.w1 : (j == 2u ? b.w2 : b.w3));
 }
 // (float)(random_double() - 0.5f)   [sample_square, random.number.gen.hpp:16]:  (u - 2^31) * 2^-32, exact in double
 DEV float draw_centered(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 2.3283064365386963e-10f; }
 // (float)random_double(-1, 1)       [random.number.gen.hpp:12-14]:  -1 + 2u*2^-32 = (u - 2^31) * 2^-31, exact in double
 DEV float draw_pm1(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 4.6566128730773926e-10f; }
 
-// random_unit_vector, random.number.gen.hpp:21-29 (`> 1e-160` on a float is `> 0`)
-DEV V3 random_unit_vector(Rng& r, uint64_t seed) {
-    for (;;) {
-        r.k = (r.k + 3u) & ~3u; // every attempt takes one whole Philox block (see coop_unit_vector)
-        const float x = draw_pm1(rng_u32(r, seed));
-        const float y = draw_pm1(rng_u32(r, seed));
-        const float z = draw_pm1(rng_u32(r, seed));
-        const V3 p = mk(x, y, z);
-        const float l2 = vdot(p, p);
-        r.k = (r.k + 3u) & ~3u;
-        if (l2 > 0.0f && l2 <= 1.0f) return vdivs(p, __builtin_sqrtf(l2));
-    }
-}
-
-// Cooperative form of the same loop, called by ALL lanes of a wave.  A rejection loop costs the wave its longest run
+// random_unit_vector, random.number.gen.hpp:21-29 (`> 1e-160` on a float is `> 0`), in cooperative form: called by
+// ALL lanes of a wave.  A rejection loop costs the wave its longest run
 // of rejections (6.6 passes for 1.9 attempts per lane at 52 % acceptance).  The draws are counter based, so any lane
 // can evaluate any attempt of any other lane's stream: every attempt takes one whole Philox block (it starts at a
 // block boundary and skips the fourth word), and each pass spreads the lanes still without a vector over all 64
@@ -208,7 +202,7 @@ DEV V3 coop_unit_vector(bool need, Rng& rng, uint64_t seed, volatile uint8_t* tb
         bool ok = false;
         V3 u = mk(0.0f, 0.0f, 0.0f);
         if (helper) {
-            Rng tmp;
+            Blk tmp;
             philox4x32_10((kb >> 2) + a, smp, pix, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), tmp);
             const V3 q = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
             const float l2 = vdot(q, q);
@@ -243,7 +237,7 @@ DEV V3 coop_unit_vector(bool need, Rng& rng, uint64_t seed, volatile uint8_t* tb
 // lane state machine
 // ---------------------------------------------------------------------------------------------------------
 enum : uint32_t { PH_FETCH = 0, PH_GEN = 1, PH_TRAV = 2, PH_SHADE = 3, PH_DONE = 4, PH_BEGIN = 5 };
-constexpr uint32_t kAttLds = 8; // closed attenuation runs kept in LDS per lane; more material changes spill to HBM
+constexpr uint32_t kAttLds = 4; // closed attenuation runs kept in LDS per lane; more material changes spill to HBM
 
 struct Trav { // per-segment traversal state
     V3 o, d;
@@ -370,8 +364,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     // write-backs per 1080p x 512 spp frame, all of it this strip.
     const uint32_t maxdepth = P.cam.maxdepth;
     uint32_t run_h = 0, run_n = 0;
-    V3 pend0 = mk(0.0f, 0.0f, 0.0f), pend1 = pend0, pend2 = pend0; // finished samples waiting for their 64-byte line
-    uint32_t npend = 0;
+    uint32_t npend = 0; // 1: a finished sample waits in `sum` for its partner of the same 32-byte sector
     auto att_store = [&](uint32_t q, uint32_t h, uint32_t n) {
         if (!BIG && q < kAttLds) {
             lds_att[q * blockDim.x + threadIdx.x] = h | (n << 16);
@@ -461,7 +454,6 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                     depth_left = r2.x >> 16;
                     rng.k = r2.y;
                     rng.sample = s;
-                    if (rng.k & 3u) philox4x32_10(rng.k >> 2, rng.sample, rng.pixel, 0u, (uint32_t)P.seed, (uint32_t)(P.seed >> 32), rng);
                     natt = r2.z & 0xffffu;
                     run_n = r2.z >> 16;
                     run_h = r2.w;
@@ -502,19 +494,23 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
             rng.k = 0;
             rng.sample = s;
             rng.pixel = gy * W + px;
-            const float offx = draw_centered(rng_u32(rng, P.seed));
-            const float offy = draw_centered(rng_u32(rng, P.seed));
+            Blk gb = rng_block(rng, 0u, P.seed); // draws 0,1: pixel jitter; 2,3: first defocus-disk attempt
+            const float offx = draw_centered(gb.w0);
+            const float offy = draw_centered(gb.w1);
+            rng.k = 2;
             const V3 du = ld3(P.cam.pixel_delta_u), dv = ld3(P.cam.pixel_delta_v);
             const V3 pixel_sample =
                 vadd(vadd(ld3(P.cam.pixel00), vscale(du, (float)px + offx)), vscale(dv, (float)gy + offy));
             V3 origin = ld3(P.cam.cam_center);
             if (!(P.cam.defocus_angle <= 0.0f)) {
                 // random_vector_on_unit_disk, random.number.gen.hpp:35-42
-                float dx, dy;
-                for (;;) {
-                    dx = draw_pm1(rng_u32(rng, P.seed));
-                    dy = draw_pm1(rng_u32(rng, P.seed));
-                    if (vdot(mk(dx, dy, 0.0f), mk(dx, dy, 0.0f)) < 1.0f) break;
+                float dx = draw_pm1(gb.w2), dy = draw_pm1(gb.w3);
+                rng.k = 4;
+                while (!(vdot(mk(dx, dy, 0.0f), mk(dx, dy, 0.0f)) < 1.0f)) { // two attempts per further block
+                    if ((rng.k & 3u) == 0u) gb = rng_block(rng, rng.k >> 2, P.seed);
+                    dx = draw_pm1((rng.k & 3u) ? gb.w2 : gb.w0);
+                    dy = draw_pm1((rng.k & 3u) ? gb.w3 : gb.w1);
+                    rng.k += 2u;
                 }
                 origin = vadd(vadd(ld3(P.cam.cam_center), vscale(ld3(P.cam.defocus_disk_u), dx)),
                               vscale(ld3(P.cam.defocus_disk_v), dy));
@@ -772,10 +768,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                             // the drain launch will store (and count) this sample; write out the finished ones that
                             // were waiting for it and move on to the next one
                             if (npend > 0u) {
-                                float4* dst = P.sample_buf + (size_t)((size_t)ply * W + px) * spp + (s - npend);
-                                dst[0] = make_float4(pend0.x, pend0.y, pend0.z, 0.0f);
-                                if (npend > 1u) dst[1] = make_float4(pend1.x, pend1.y, pend1.z, 0.0f);
-                                if (npend > 2u) dst[2] = make_float4(pend2.x, pend2.y, pend2.z, 0.0f);
+                                P.sample_buf[(size_t)((size_t)ply * W + px) * spp + (s - 1u)] = make_float4(sum.x, sum.y, sum.z, 0.0f);
                                 npend = 0u;
                             }
                             s++;
@@ -812,22 +805,17 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
             if (ended) {
                 // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
                 if (P.sample_buf) {
-                    // 16-byte sample records, written a 64-byte line at a time: up to three finished samples wait in
-                    // registers until the fourth of their line (or the end of the chunk) arrives, so that the four
-                    // stores hit L2 back to back and leave it as one full line (a lone 16-byte store costs ~43 bytes
-                    // of write-back at the fabric, measured)
-                    if ((s & 3u) == 3u || s + 1u >= s_end) {
+                    // 16-byte sample records, written a 32-byte sector at a time: an even sample waits in registers for
+                    // its odd partner (or the end of the chunk), so that the two stores hit L2 back to back and leave
+                    // it as one full sector (a lone 16-byte store costs ~43 bytes of write-back at the fabric, measured)
+                    if ((s & 1u) == 1u || s + 1u >= s_end) {
                         float4* dst = P.sample_buf + (size_t)((size_t)ply * W + px) * spp + (s - npend);
-                        if (npend > 0u) dst[0] = make_float4(pend0.x, pend0.y, pend0.z, 0.0f);
-                        if (npend > 1u) dst[1] = make_float4(pend1.x, pend1.y, pend1.z, 0.0f);
-                        if (npend > 2u) dst[2] = make_float4(pend2.x, pend2.y, pend2.z, 0.0f);
+                        if (npend > 0u) dst[0] = make_float4(sum.x, sum.y, sum.z, 0.0f);
                         dst[npend] = make_float4(color.x, color.y, color.z, 0.0f);
                         npend = 0u;
                     } else {
-                        if (npend == 0u) pend0 = color;
-                        else if (npend == 1u) pend1 = color;
-                        else pend2 = color;
-                        npend++;
+                        sum = color; // `sum` is free in this mode: it holds the waiting sample
+                        npend = 1u;
                     }
                 } else {
                     sum = vadd(sum, color);
@@ -961,7 +949,7 @@ struct rtmi_scene {
     uint32_t defer_cap = 0;
     bool defer_enabled = true;
     // launch geometry
-    uint32_t block = 512, grid = 0, lds_bytes = 0, stack_depth = 0;
+    uint32_t block = 768, grid = 0, lds_bytes = 0, stack_depth = 0; // 2 x 768 lanes per CU = 6 waves per SIMD (<= 80 VGPRs)
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
     uint32_t wait_thresh = 56; // lanes waiting for shading that end a traversal round (A/B on MI355X: 56 best)
     uint32_t lds_att = 0, lds_pool = 0;
