@@ -16,7 +16,11 @@ def make(width, spp, depth, env, accel=None, stats=False):
 if __name__ == "__main__":
     w = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    variants = {"w56": dict(), "1blk": dict(RTMI_BLOCKS_PER_CU=1), "b256x2": dict(RTMI_BLOCK=256, RTMI_BLOCKS_PER_CU=2), "b256x3": dict(RTMI_BLOCK=256, RTMI_BLOCKS_PER_CU=3), "b256x4": dict(RTMI_BLOCK=256)}
+    variants = {"w56": dict()}
+    for wt in (44, 50, 60):
+        variants[f"w{wt}"] = dict(RTMI_WAIT_THRESH=wt)
+    for dw in (48, 62):
+        variants[f"dw{dw}"] = dict(RTMI_DRAIN_WAIT=dw)
     scenes = {k: make(w, spp, 50, v) for k, v in variants.items()}
     ref = None
     res = {k: [] for k in scenes}
