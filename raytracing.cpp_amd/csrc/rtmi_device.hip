@@ -50,8 +50,8 @@ struct RtmiLaunch {
     rtmi_camera cam;
     // scene, global memory (staged into LDS by every workgroup)
     const uint4* spheres;  // [n_slots] {cx, cy, cz, r*r} as bits
-    const uint4* aux;      // [n_slots] {object index, material handle, radius bits, 0}
-    const uint4* mats;     // [n_mats]  2 x uint4 per material: {kind, p0, p1, p2}, {p3, 0, 0, 0}
+    const uint4* aux;      // [n_slots] {object index, material handle, radius bits, MaterialKind of that handle}
+    const uint4* mats;     // [n_mats]  {p0, p1, p2, p3} (albedo + fuzz, or refraction index in p0); the kind rides in aux.w
     const uint4* nodes;    // [n_nodes] 4 x uint4 per node (rtmi_bvh_node)
     uint32_t n_slots, n_mats, n_nodes, root_ref, n_top_nodes;
     float pad_classes[kMaxPadClasses][8];
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
             w_spheres[i] = P.spheres[i];
             w_aux[i] = P.aux[i];
         }
-        for (uint32_t i = threadIdx.x; i < 2u * P.n_mats; i += blockDim.x) w_mats[i] = P.mats[i];
+        for (uint32_t i = threadIdx.x; i < P.n_mats; i += blockDim.x) w_mats[i] = P.mats[i];
         if (ACCEL == RTMI_ACCEL_BVH) {
             for (uint32_t i = threadIdx.x; i < 4u * P.n_nodes; i += blockDim.x) w_nodes[i] = P.nodes[i];
         }
@@ -383,8 +383,8 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
         }
     };
     auto att_apply = [&](V3 color, uint32_t h, uint32_t n) -> V3 {
-        const uint4 m0 = lds_mats[2u * h];
-        const V3 a = mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w));
+        const uint4 m0 = lds_mats[h];
+        const V3 a = mk(__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z));
         for (uint32_t c = 0; c < n; ++c) color = vmul(a, color); // A*(A*(...)): one multiply per bounce, in order
         return color;
     };
@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
         // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
         // unit vectors for every Lambertian / Metallic hit of this round, generated by the whole wave together
         bool need_unit = false;
-        if (phase == PH_SHADE && t.cur != 0xfffffffeu && t.best != ~0u) need_unit = lds_mats[2u * lds_aux[t.best].y].x != 2u;
+        if (phase == PH_SHADE && t.cur != 0xfffffffeu && t.best != ~0u) need_unit = lds_aux[t.best].w != 2u;
         const V3 unit_vec = coop_unit_vector(need_unit, rng, P.seed, rank_tbl);
         if (phase == PH_SHADE) {
             bool ended = false;
@@ -678,9 +678,8 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                 const bool front = vdot(t.d, outward) < 0.0f;
                 const V3 N = front ? outward : vneg(outward);
                 const uint32_t mh = araw.y;
-                const uint4 m0 = lds_mats[2u * mh], m1 = lds_mats[2u * mh + 1u];
-                const uint32_t kind = m0.x;
-                const V3 albedo = mk(__uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w));
+                const uint4 m0 = lds_mats[mh]; // {albedo, fuzz} or {refraction index, ...}
+                const uint32_t kind = araw.w;
                 V3 sd = mk(0.0f, 0.0f, 0.0f);
                 bool scattered = true;
                 PF_MARK(pf3);
@@ -695,12 +694,12 @@ __global__ void __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
                         const float eps = 1e-8f; // near_zero, ray.tracer.math.hpp:16-19
                         if (__builtin_fabsf(sd.x) < eps && __builtin_fabsf(sd.y) < eps && __builtin_fabsf(sd.z) < eps) sd = N;
                     } else {
-                        sd = vadd(rn, vscale(u, __uint_as_float(m1.x)));
+                        sd = vadd(rn, vscale(u, __uint_as_float(m0.w)));
                         scattered = vdot(sd, N) > 0.0f;
                     }
                     PF_MARK(pf4);
                 } else { // Material_Dielectric::scatter, material.defs.cc:57-87
-                    const float ri = __uint_as_float(m0.y);
+                    const float ri = __uint_as_float(m0.x);
                     const float eta = front ? (1.0f / ri) : ri;
                     const V3 unit_dir = vnormalize(t.d);
                     const float cos_theta = fminf(vdot(vneg(unit_dir), N), 1.0f);
@@ -1229,7 +1228,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
         for (uint32_t i = 0; i < n_objects; ++i) slot_object[i] = i;
         s->bvh.root_ref = 0;
     }
-    std::vector<uint4> h_spheres(n_objects), h_aux(n_objects), h_mats(2 * (size_t)n_materials);
+    std::vector<uint4> h_spheres(n_objects), h_aux(n_objects), h_mats((size_t)n_materials);
     auto fbits = [](float f) {
         uint32_t u;
         std::memcpy(&u, &f, 4);
@@ -1240,12 +1239,11 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
         // Radius * Radius of object.defs.cc:46 is the same float for every ray: computed once here
         const float r2 = o.radius * o.radius;
         h_spheres[i] = make_uint4(fbits(o.center[0]), fbits(o.center[1]), fbits(o.center[2]), fbits(r2));
-        h_aux[i] = make_uint4(slot_object[i], o.material, fbits(o.radius), 0u);
+        h_aux[i] = make_uint4(slot_object[i], o.material, fbits(o.radius), materials[o.material].kind);
     }
     for (uint32_t i = 0; i < n_materials; ++i) {
         const rtmi_material& m = materials[i];
-        h_mats[2 * i] = make_uint4(m.kind, fbits(m.p[0]), fbits(m.p[1]), fbits(m.p[2]));
-        h_mats[2 * i + 1] = make_uint4(fbits(m.p[3]), 0u, 0u, 0u);
+        h_mats[i] = make_uint4(fbits(m.p[0]), fbits(m.p[1]), fbits(m.p[2]), fbits(m.p[3]));
     }
 
     if (const char* e = std::getenv("RTMI_BLOCK")) s->block = (uint32_t)std::min(1024, std::max(64, (std::atoi(e) / 64) * 64));
@@ -1253,7 +1251,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     // stay in HBM and only the traversal stack is in LDS.
     auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
     s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) : 0u;
-    const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 32u;
+    const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 16u;
     const uint64_t small_total = scene_bytes + (uint64_t)s->stack_depth * s->block * 2u + 64u;
     s->big = small_total + kAttLds * s->block * 4u > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u ||
              n_objects > 0x2000u || n_materials > 0x10000u;
@@ -1267,7 +1265,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
         s->lds_aux = off;
         off += n_objects * 16u;
         s->lds_mats = off;
-        off += n_materials * 32u;
+        off += n_materials * 16u;
         off = align16(off);
     }
     if (s->big && s->accel == RTMI_ACCEL_BVH) {
