@@ -1,0 +1,38 @@
+// render_ppm.cpp -- smallest complete host program on top of the mirror header: scene file in the reference's schema
+// (data/config/world.config.json) -> RayTracingCore::default_setup -> one frame on the GPU -> binary PPM.
+//
+//   g++ -std=c++17 -O2 -Iinclude -Iraytracing.cpp_amd/host raytracing.cpp_amd/host/render_ppm.cpp \
+//       -Lraytracing.cpp_amd -lrtmi -lpthread -Wl,-rpath,$PWD/raytracing.cpp_amd -o render_ppm
+//   ./render_ppm data/config/world.config.json out.ppm [scene_seed] [frame_seed]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+#include "rtmi_raytracer.hpp"
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s <world.config.json> <out.ppm> [scene_seed] [frame_seed]\n", argv[0]);
+        return 2;
+    }
+    const uint32_t scene_seed = argc > 3 ? static_cast<uint32_t>(std::strtoul(argv[3], nullptr, 10)) : 12345u;
+    const uint64_t frame_seed = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 1ull;
+    try {
+        auto core = rtmi::RayTracingCore::default_setup(scene_seed, argv[1]);
+        std::vector<rtmi::RGBAColor> frame(size_t(core->rts_img_width) * core->rts_img_height);
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = core->raytrace_rows(0, core->rts_img_height, frame_seed, frame.data());
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc != RTMI_OK) {
+            std::fprintf(stderr, "rtmi: %s\n", rtmi_last_error());
+            return 1;
+        }
+        const double samples = double(frame.size()) * core->rts_samples_per_pixel;
+        std::printf("%ux%u, %u spp, %zu objects: %.3f s, %.1f Msamples/s\n", core->rts_img_width, core->rts_img_height,
+                    core->rts_samples_per_pixel, core->rts_world.size(), secs, samples / secs / 1e6);
+        return rtmi::write_ppm(argv[2], core->rts_img_width, core->rts_img_height, frame.data()) ? 0 : 1;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

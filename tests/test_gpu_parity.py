@@ -166,6 +166,45 @@ def test_scheduling_knobs_do_not_change_the_image(pkg, ob, rtow, gpu, monkeypatc
         assert st["samples"] == cam.img_width * cam.img_height * 96, env
 
 
+def test_random_scenes_and_cameras(pkg, ob, gpu):
+    """Forty random worlds -- overlapping and nested spheres, cameras inside spheres, fuzz > 1 (clamped at
+    construction), refraction indices below 1, huge and tiny radii, shared material handles -- through both accel
+    paths against the oracle."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n = int(rng.integers(1, 60))
+        n_mats = int(rng.integers(1, n + 1))
+        objs = np.zeros(n, pkg.OBJECT_DTYPE)
+        mats = np.zeros(n_mats, pkg.MATERIAL_DTYPE)
+        for m in range(n_mats):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                mats[m] = (0, (*rng.uniform(0.0, 1.0, 3), 0.0))
+            elif kind == 1:
+                mats[m] = (1, (*rng.uniform(0.3, 1.0, 3), min(1.0, float(rng.uniform(0.0, 1.6)))))
+            else:
+                mats[m] = (2, (float(rng.uniform(0.6, 2.2)), 0.0, 0.0, 0.0))
+        scale = float(rng.choice([0.5, 3.0, 30.0]))
+        for i in range(n):
+            r = float(rng.choice([0.05, 0.3, 1.0, 4.0, 200.0])) * float(rng.uniform(0.5, 1.5))
+            objs[i] = (0, tuple(rng.uniform(-scale, scale, 3)), r, int(rng.integers(0, n_mats)))
+        kw = dict(image_width=int(rng.integers(17, 64)), aspect_ratio=float(rng.choice([1.0, 16.0 / 9.0, 2.35])),
+                  samples_per_pixel=int(rng.integers(1, 9)), max_depth=int(rng.choice([1, 3, 12, 50])),
+                  vertical_fov=float(rng.uniform(10.0, 110.0)), defocus_angle=float(rng.choice([0.0, 0.6, 8.0])),
+                  focus_distance=float(rng.uniform(0.5, 12.0)), lookfrom=tuple(rng.uniform(-scale, scale, 3)),
+                  lookat=tuple(rng.uniform(-1.0, 1.0, 3)), world_up=(0.0, 1.0, 0.0))
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        if cam.img_height == 0:
+            continue
+        seed = int(rng.integers(0, 2 ** 62))
+        want, want8 = ob.render_rect_counter(ocam, objs, mats, seed, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
+        for accel, name in _both(pkg):
+            with pkg.Scene(cam, objs, mats, accel=accel) as s:
+                rgb, rgba = s.render_rows(0, cam.img_height, seed)
+            _assert_frames_equal(rgb, want)
+            assert np.array_equal(rgba, want8), (case, name)
+
+
 def test_degenerate_scenes(pkg, ob, gpu):
     kw = dict(image_width=40, samples_per_pixel=2, max_depth=5)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))

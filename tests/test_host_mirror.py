@@ -150,3 +150,14 @@ def test_job_system_adapter_streams_row_blocks_into_the_display(exe, ob, tmp_pat
     assert hdr == b"P6\n160 90"
     rgb = np.frombuffer(body, np.uint8).reshape(90, 160, 3)
     assert np.array_equal(rgb[..., 0], (want8 & 0xff).astype(np.uint8)) and np.array_equal(rgb[..., 2], ((want8 >> 16) & 0xff).astype(np.uint8))
+
+
+def test_example_program_builds(pkg, tmp_path):
+    """raytracing.cpp_amd/host/render_ppm.cpp (scene file -> frame -> PPM) compiles and links against librtmi.so."""
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    out = str(tmp_path / "render_ppm")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(libdir, "host"),
+                    os.path.join(libdir, "host", "render_ppm.cpp"), "-o", out, "-L", libdir, "-lrtmi", "-lpthread",
+                    f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([out], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
