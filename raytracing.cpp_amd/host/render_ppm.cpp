@@ -1,7 +1,7 @@
 // render_ppm.cpp -- smallest complete host program on top of the mirror header: scene file in the reference's schema
 // (data/config/world.config.json) -> RayTracingCore::default_setup -> one frame on the GPU -> binary PPM.
 //
-//   g++ -std=c++17 -O2 -Iinclude -Iraytracing.cpp_amd/host raytracing.cpp_amd/host/render_ppm.cpp \
+//   g++ -std=c++17 -O2 -Iinclude -Iraytracing.cpp_amd/host raytracing.cpp_amd/host/render_ppm.cpp
 //       -Lraytracing.cpp_amd -lrtmi -lpthread -Wl,-rpath,$PWD/raytracing.cpp_amd -o render_ppm
 //   ./render_ppm data/config/world.config.json out.ppm [scene_seed] [frame_seed]
 #include <chrono>
