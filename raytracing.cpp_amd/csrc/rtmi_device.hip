@@ -193,6 +193,9 @@ DEV uint32_t rng_u32(Rng& r, uint64_t seed) { // one draw at the current positio
 // (float)(random_double() - 0.5f)   [sample_square, random.number.gen.hpp:16]:  (u - 2^31) * 2^-32, exact in double
 DEV float draw_centered(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 2.3283064365386963e-10f; }
 // (float)random_double(-1, 1)       [random.number.gen.hpp:12-14]:  -1 + 2u*2^-32 = (u - 2^31) * 2^-31, exact in double
+// wave-wide vote straight from the compare (HIP's __ballot goes through an int and a second compare)
+DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 DEV float draw_pm1(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 4.6566128730773926e-10f; }
 
 // random_unit_vector, random.number.gen.hpp:21-29 (`> 1e-160` on a float is `> 0`), in cooperative form: called by
@@ -206,7 +209,7 @@ DEV V3 coop_unit_vector(bool need, Rng& rng, uint64_t seed, volatile uint8_t* tb
     V3 out = mk(0.0f, 0.0f, 0.0f);
     if (need) rng.k = (rng.k + 3u) & ~3u; // attempts are block aligned
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    uint64_t todo = __ballot(need);
+    uint64_t todo = ballot(need);
     bool pending = need;
     while (todo != 0ull) {
         const uint32_t n = (uint32_t)__popcll(todo);
@@ -222,18 +225,15 @@ DEV V3 coop_unit_vector(bool need, Rng& rng, uint64_t seed, volatile uint8_t* tb
         const uint32_t smp = (uint32_t)__shfl((int)rng.sample, (int)src);
         const uint32_t kb = (uint32_t)__shfl((int)rng.k, (int)src);
         bool ok = false;
-        V3 u = mk(0.0f, 0.0f, 0.0f);
+        V3 u = mk(0.0f, 0.0f, 0.0f); // the accepted point, not yet normalised
         if (helper) {
             Blk tmp;
             philox4x32_10((kb >> 2) + a, smp, pix, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), tmp);
-            const V3 q = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
-            const float l2 = vdot(q, q);
-            if (l2 > 0.0f && l2 <= 1.0f) { // random.number.gen.hpp:25-27
-                ok = true;
-                u = vdivs(q, __builtin_sqrtf(l2));
-            }
+            u = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
+            const float l2 = vdot(u, u);
+            ok = l2 > 0.0f && l2 <= 1.0f; // random.number.gen.hpp:25-27
         }
-        const uint64_t okm = __ballot(ok);
+        const uint64_t okm = ballot(ok);
         // the pending lane takes its first accepted attempt, in attempt order
         uint32_t first = per;
 #pragma unroll
@@ -250,8 +250,10 @@ DEV V3 coop_unit_vector(bool need, Rng& rng, uint64_t seed, volatile uint8_t* tb
         } else if (pending) {
             rng.k += 4u * per;
         }
-        todo = __ballot(pending);
+        todo = ballot(pending);
     }
+    // p / sqrt(dot(p, p)) once, on the owner's lane: the IEEE square root and divisions are not paid per attempt
+    if (need) out = vdivs(out, __builtin_sqrtf(vdot(out, out)));
     return out;
 }
 
@@ -267,7 +269,7 @@ struct Trav { // per-segment traversal state
     float tbest;      // closest accepted root so far (Interval::Max, object.defs.cc:69)
     uint32_t best;    // slot of the closest sphere, ~0u = none
     uint32_t cur;     // BVH: current node/leaf reference; brute force: unused
-    uint32_t sp;      // BVH: stack entries
+    uint32_t sp;      // BVH: LDS byte address of the next free entry of this lane's stack ([depth][lane] array)
     V3 inv, oinv, pinv; // BVH slab test: 1/d, -o/d, pad*|1/d|
 };
 
@@ -321,7 +323,10 @@ template <int ACCEL, bool STATS, bool BIG, bool DRAIN>
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
-    StackT* lds_stack = reinterpret_cast<StackT*>(lds_raw + P.lds_stack);
+    // traversal stack: entry 0 of every lane holds a sentinel that ends the walk when it is popped
+    constexpr uint32_t kStackEnd = BIG ? 0xffffffffu : 0xffffu;
+    const uint32_t sp0 = P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT), sp_stride = blockDim.x * (uint32_t)sizeof(StackT);
+    if (ACCEL == RTMI_ACCEL_BVH) *reinterpret_cast<StackT*>(lds_raw + sp0) = (StackT)kStackEnd;
     uint32_t* lds_att = reinterpret_cast<uint32_t*>(lds_raw + P.lds_att);
     // per-wave pools: work indices and deferred-path slots are taken from the global counters 64 at a time (a single
     // counter word saturates at ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M
@@ -342,7 +347,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
         lds_mats = P.mats;
         lds_nodes = P.nodes;
         if (ACCEL == RTMI_ACCEL_BVH && P.n_top_nodes) {
-            uint4* w_top = reinterpret_cast<uint4*>(lds_raw + P.lds_nodes);
+            uint4* w_top = reinterpret_cast<uint4*>(lds_raw); // nodes always start the dynamic LDS segment
             for (uint32_t i = threadIdx.x; i < 4u * P.n_top_nodes; i += blockDim.x) w_top[i] = P.nodes[i];
             __syncthreads();
             top_nodes = w_top;
@@ -352,7 +357,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
         uint4* w_spheres = reinterpret_cast<uint4*>(lds_raw + P.lds_spheres);
         uint4* w_aux = reinterpret_cast<uint4*>(lds_raw + P.lds_aux);
         uint4* w_mats = reinterpret_cast<uint4*>(lds_raw + P.lds_mats);
-        uint4* w_nodes = reinterpret_cast<uint4*>(lds_raw + P.lds_nodes);
+        uint4* w_nodes = reinterpret_cast<uint4*>(lds_raw); // nodes always start the dynamic LDS segment
         for (uint32_t i = threadIdx.x; i < P.n_slots; i += blockDim.x) {
             w_spheres[i] = P.spheres[i];
             w_aux[i] = P.aux[i];
@@ -412,13 +417,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
         for (uint32_t c = 0; c < n; ++c) color = vmul(a, color); // A*(A*(...)): one multiply per bounce, in order
         return color;
     };
+    const uint32_t sp1 = sp0 + sp_stride;
     auto begin_segment = [&](V3 o, V3 d) {
         t.o = o;
         t.d = d;
         t.a = vdot(d, d);
         t.tbest = __builtin_inff();
         t.best = ~0u;
-        t.sp = 0;
+        t.sp = sp1;
         if (ACCEL == RTMI_ACCEL_BVH) {
             t.cur = P.root_ref;
             t.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
@@ -443,7 +449,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
         PF_COUNT(pf10);
         // ---- FETCH: one wave-aggregated atomic hands out consecutive indices of the 8x8-tiled pixel space -----
         while (phase == PH_FETCH) {
-            const uint64_t need = __ballot(1);
+            const uint64_t need = ballot(true);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             uint32_t start = 0, take = 0;
             if (rank == 0) { // the wave's leader serves the request from the wave's pool, refilling it 64 items at a time
@@ -508,9 +514,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                 }
             }
         }
-        if (__ballot(phase != PH_DONE) == 0ull) break;
+        if (ballot(phase != PH_DONE) == 0ull) break;
         PF_MARK(pf0);
-        PF_LANES(pl5, __ballot(phase == PH_GEN));
+        PF_LANES(pl5, ballot(phase == PH_GEN));
 
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
         if (!DRAIN && phase == PH_GEN) {
@@ -555,29 +561,34 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
             }
         }
         // every new segment of this round -- primary rays, scattered rays, resumed paths -- is set up here, once
+        PF_MARK(pf1);
         if (phase == PH_BEGIN) {
+            PF_LANES(pl6, ballot(true));
             begin_segment(t.o, t.d);
             phase = PH_TRAV;
         }
 
-        PF_MARK(pf1);
+        PF_MARK(pf6);
         // ---- TRAVERSE ---------------------------------------------------------------------------------------------
         if (ACCEL == RTMI_ACCEL_BVH) {
             // Two kinds of step: an internal node (two slab tests) or a leaf (its spheres).  Each iteration the wave
             // runs only the kind that holds more of its traversing lanes; the other lanes keep their place.
+            // leave when wait_thresh lanes wait for shading; the stragglers keep their state and go on next round
+            // (A/B on MI355X: counting finished lanes as waiting too was 0-5 % slower).  Inside the loop lanes only move
+            // from TRAV to SHADE, so the test is on the number still traversing: no third vote, no reload per trip.
+            const int trav_floor = (int)__popcll(ballot(phase == PH_TRAV || phase == PH_SHADE)) - (int)P.wait_thresh;
             for (;;) {
                 // LDS-resident scenes carry their node/leaf references in the 16-bit form of the stack entries
                 // (0x8000 | (count-1) << 13 | first slot for a leaf): no packing or unpacking on push / pop
-                const bool at_leaf = (t.cur & (BIG ? kLeafBit : 0x8000u)) != 0u;
-                const uint64_t m_node = __ballot(phase == PH_TRAV && !at_leaf);
-                const uint64_t m_leaf = __ballot(phase == PH_TRAV && at_leaf);
-                if ((m_node | m_leaf) == 0ull) break;
+                const bool at_leaf = t.cur >= (BIG ? kLeafBit : 0x8000u);
+                const uint64_t m_trav = ballot(phase == PH_TRAV);
+                const uint64_t m_leaf = ballot(at_leaf) & m_trav;
+                const uint64_t m_node = m_trav & ~m_leaf;
+                if (m_trav == 0ull) break;
                 PF_COUNT(pf11);
                 if (__popcll(m_leaf) > __popcll(m_node)) { PF_COUNT(pl0); PF_LANES(pl1, m_leaf); } else { PF_LANES(pl2, m_node); }
-                // leave when wait_thresh lanes wait for shading; the stragglers keep their state and go on next round
-                // (A/B on MI355X: counting finished lanes as waiting too was 0-5 % slower)
-                const uint32_t n_leaf = (uint32_t)__popcll(m_leaf), n_node = (uint32_t)__popcll(m_node);
-                if ((uint32_t)__popcll(__ballot(phase == PH_SHADE)) >= P.wait_thresh) break;
+                const int n_leaf = (int)__popcll(m_leaf), n_node = (int)__popcll(m_node);
+                if (n_leaf + n_node <= trav_floor) break;
                 bool pop = false;
                 if (n_leaf > n_node) {
                     if (phase == PH_TRAV && at_leaf) {
@@ -626,12 +637,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                     const uint32_t ch0 = n3.x, ch1 = n3.y;
                     asm volatile("" ::"v"(ch0), "v"(ch1)); // keep the child-reference read with the box reads (one LDS round trip)
                     if (hit0 || hit1) {
-                        const bool both = hit0 && hit1;
-                        const bool take1 = both ? (tn1 < tn0) : hit1;
-                        if (both) {
-                            const uint32_t far_ref = take1 ? ch0 : ch1;
-                            lds_stack[t.sp * blockDim.x + threadIdx.x] = (StackT)far_ref;
-                            t.sp++;
+                        const bool take1 = hit1 && (!hit0 || tn1 < tn0); // nearer child first
+                        if (hit0 && hit1) {
+                            *reinterpret_cast<StackT*>(lds_raw + t.sp) = (StackT)(take1 ? ch0 : ch1);
+                            t.sp += sp_stride;
                         }
                         t.cur = take1 ? ch1 : ch0;
                     } else {
@@ -639,18 +648,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                     }
                 }
                 if (pop) {
-                    if (t.sp == 0) {
-                        phase = PH_SHADE;
-                    } else {
-                        t.sp--;
-                        t.cur = lds_stack[t.sp * blockDim.x + threadIdx.x];
-                    }
+                    t.sp -= sp_stride;
+                    t.cur = *reinterpret_cast<const StackT*>(lds_raw + t.sp);
+                    if (t.cur == kStackEnd) phase = PH_SHADE; // the sentinel: stack empty
                 }
             }
         } else {
             // the reference's linear closest-hit scan (object.defs.cc:68-81); all lanes of a wave read the same
             // sphere, so every LDS read is a broadcast.
-            if (__ballot(phase == PH_TRAV) != 0ull) {
+            if (ballot(phase == PH_TRAV) != 0ull) {
                 if (phase == PH_TRAV) {
                     uint32_t i = 0;
                     for (; i + 4u <= P.n_slots; i += 4u) { // four broadcast reads in flight, four discriminants, then the rare roots
@@ -679,14 +685,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
         }
 
         PF_MARK(pf2);
-        PF_LANES(pl3, __ballot(phase == PH_SHADE));
-        PF_LANES(pl4, __ballot(phase == PH_SHADE && t.best == ~0u));
-        PF_LANES(pl7, __ballot(phase == PH_DONE));
+        PF_LANES(pl3, ballot(phase == PH_SHADE));
+        PF_LANES(pl4, ballot(phase == PH_SHADE && t.best == ~0u));
+        PF_LANES(pl7, ballot(phase == PH_DONE));
         // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
         // unit vectors for every Lambertian / Metallic hit of this round, generated by the whole wave together
         bool need_unit = false;
         if (phase == PH_SHADE && t.cur != 0xfffffffeu && t.best != ~0u) need_unit = lds_aux[t.best].w != 2u;
+        PF_MARK(pf8);
         const V3 unit_vec = coop_unit_vector(need_unit, rng, P.seed, rank_tbl);
+        PF_MARK(pf5);
         if (phase == PH_SHADE) {
             bool ended = false;
             V3 color = mk(0.0f, 0.0f, 0.0f);
@@ -707,7 +715,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                 const uint32_t kind = araw.w;
                 V3 sd = mk(0.0f, 0.0f, 0.0f);
                 bool scattered = true;
-                PF_MARK(pf3);
                 if (kind != 2u) {
                     // Lambertian (material.defs.cc:31-42) and Metallic (:44-55) share ONE rejection loop for their
                     // random_unit_vector(): the wave pays the longest run of rejections once, not once per material.
@@ -722,7 +729,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                         sd = vadd(rn, vscale(u, __uint_as_float(m0.w)));
                         scattered = vdot(sd, N) > 0.0f;
                     }
-                    PF_MARK(pf4);
                 } else { // Material_Dielectric::scatter, material.defs.cc:57-87
                     const float ri = __uint_as_float(m0.x);
                     const float eta = front ? (1.0f / ri) : ri;
@@ -742,9 +748,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                         reflect_it = (double)schlick > u;
                     }
                     sd = reflect_it ? vreflect(unit_dir, N) : vrefract(unit_dir, N, eta);
-                    PF_MARK(pf6);
                 }
-                PF_MARK(pf8);
                 if (!scattered) {
                     ended = true; // absorbed: compute_color returns 0 (core.cc:251)
                 } else {
@@ -756,7 +760,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                         bool deferred = false;
                         if (!DRAIN && !BIG && P.defer_buf && !front && kind != 2u && natt <= 4u && depth_left >= 8u) {
                             // wave-aggregated append to the deferred-path queue (ballot + prefix popcount)
-                            const uint64_t m = __ballot(1);
+                            const uint64_t m = ballot(true);
                             const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                             uint32_t sstart = 0, stake = 0;
                             if (rk == 0) { // slots come from the wave's pool, reserved 64 at a time
@@ -823,9 +827,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                     color = att_apply(color, h, n);
                 }
                 ended = true;
-                PF_MARK(pf7);
             }
-            PF_MARK(pf8);
             if (ended) {
                 // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
                 if (P.sample_buf) {
@@ -871,6 +873,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                 }
             }
         }
+        PF_MARK(pf3);
     }
 
     if (!DRAIN && P.defer_buf && lane == 0u) { // reserved but unused slots become empty records (depth 0)
@@ -881,11 +884,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
 #ifdef RTMI_PROF
     PF_MARK(pf9);
     if (lane == 0) {
-        atomicAdd(&P.stats[8], pf0); atomicAdd(&P.stats[9], pf1); atomicAdd(&P.stats[10], pf2); atomicAdd(&P.stats[11], pf3);
-        atomicAdd(&P.stats[12], pf4); atomicAdd(&P.stats[13], pf5); atomicAdd(&P.stats[14], pf6); atomicAdd(&P.stats[15], pf7);
-        atomicAdd(&P.stats[16], pf8); atomicAdd(&P.stats[17], pf9); atomicAdd(&P.stats[18], pf10); atomicAdd(&P.stats[19], pf11);
-        atomicAdd(&P.stats[20], pl0); atomicAdd(&P.stats[21], pl1); atomicAdd(&P.stats[22], pl2); atomicAdd(&P.stats[23], pl3);
-        atomicAdd(&P.stats[24], pl4); atomicAdd(&P.stats[25], pl5); atomicAdd(&P.stats[26], pl6); atomicAdd(&P.stats[27], pl7);
+        unsigned long long* const pst = P.stats + (DRAIN ? 32 : 0); // the drain launch reports into its own block
+        atomicAdd(&pst[8], pf0); atomicAdd(&pst[9], pf1); atomicAdd(&pst[10], pf2); atomicAdd(&pst[11], pf3);
+        atomicAdd(&pst[12], pf4); atomicAdd(&pst[13], pf5); atomicAdd(&pst[14], pf6); atomicAdd(&pst[15], pf7);
+        atomicAdd(&pst[16], pf8); atomicAdd(&pst[17], pf9); atomicAdd(&pst[18], pf10); atomicAdd(&pst[19], pf11);
+        atomicAdd(&pst[20], pl0); atomicAdd(&pst[21], pl1); atomicAdd(&pst[22], pl2); atomicAdd(&pst[23], pl3);
+        atomicAdd(&pst[24], pl4); atomicAdd(&pst[25], pl5); atomicAdd(&pst[26], pl6); atomicAdd(&pst[27], pl7);
     }
 #endif
     if (STATS) {
@@ -1278,7 +1282,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     // LDS carve-up.  Small scenes live in LDS entirely (two workgroups per CU must fit: 80 KiB each); larger ones
     // stay in HBM and only the traversal stack is in LDS.
     auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-    s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) : 0u;
+    s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) + 1u : 0u; // + the sentinel entry
     const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 16u;
     const uint64_t small_total = scene_bytes + (uint64_t)s->stack_depth * s->block * 2u + 64u;
     s->big = small_total + kAttLds * s->block * 4u > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u ||
@@ -1369,8 +1373,8 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     s->grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
 
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_counter), 16));
-    HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 32 * sizeof(unsigned long long)));
-    HIP_TRY_S(hipMemset(s->d_stats, 0, 32 * sizeof(unsigned long long)));
+    HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 64 * sizeof(unsigned long long)));
+    HIP_TRY_S(hipMemset(s->d_stats, 0, 64 * sizeof(unsigned long long)));
     const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * s->grid * s->block * 2u * sizeof(uint32_t));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_att), att_bytes));
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -1503,6 +1507,6 @@ extern "C" int rtmi_scene_last_kernel_ms(rtmi_scene* s, float* ms_out) {
 extern "C" int rtmi_prof_read(rtmi_scene* s, unsigned long long* out32) {
     hipSetDevice(s->device);
     hipDeviceSynchronize();
-    return hipMemcpy(out32, s->d_stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+    return hipMemcpy(out32, s->d_stats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 #endif

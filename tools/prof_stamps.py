@@ -17,17 +17,20 @@ objs, mats = pkg.make_world_spheres(12345)
 with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
     sc.render_rows(0, cam.img_height, 7)
     ms = sc.last_kernel_ms()
-    out = (C.c_ulonglong * 32)()
+    out = (C.c_ulonglong * 64)()
     pkg.lib().rtmi_prof_read(sc._h, out)
-names = ["fetch", "gen", "traverse", "hitrec", "lambert", "metal", "dielectric", "miss", "shade-glue", "loop-glue", "#rounds", "#trav-iters"]
-v = [int(x) for x in out[8:20]]
-tot = sum(v[:10])
-print(f"kernel {ms:.1f} ms; stamped cycles (sum over waves) {tot:.3e}")
-for n, x in zip(names, v):
-    print(f"  {n:12s} {x:16d}  {100.0*x/tot if n[0] != '#' else 0:6.2f} %")
-L = [int(x) for x in out[20:28]]
-rounds, iters = v[10], v[11]
-leaf_it, node_it = L[0], iters - L[0]
-print(f"  node iters/round {node_it/rounds:.2f} mean lanes {L[2]/max(1,node_it):.1f};  leaf iters/round {leaf_it/rounds:.2f} mean lanes {L[1]/max(1,leaf_it):.1f}")
-print(f"  per round: shade lanes {L[3]/rounds:.1f} (miss {L[4]/rounds:.1f}), gen lanes {L[5]/rounds:.1f}, done lanes {L[7]/rounds:.1f}")
-print(f"  trav iters per round: {v[11]/max(1,v[10]):.2f}; cycles per trav iter: {v[2]/max(1,v[11]):.1f}; cycles per round: {tot/max(1,v[10]):.1f}")
+names = ["fetch", "gen", "traverse", "shade", "-", "coop-unit", "begin-seg", "-", "pre-coop", "loop-glue", "#rounds", "#trav-iters"]
+for label, base in (("primary", 0), ("drain", 32)):
+    v = [int(x) for x in out[base + 8:base + 20]]
+    tot = sum(v[:10])
+    if tot == 0:
+        continue
+    print(f"[{label}] kernel(s) {ms:.1f} ms; stamped cycles (sum over waves) {tot:.3e}")
+    for n, x in zip(names, v):
+        print(f"  {n:12s} {x:16d}  {100.0*x/tot if n[0] != '#' else 0:6.2f} %")
+    L = [int(x) for x in out[base + 20:base + 28]]
+    rounds, iters = v[10], v[11]
+    leaf_it, node_it = L[0], iters - L[0]
+    print(f"  node iters/round {node_it/rounds:.2f} mean lanes {L[2]/max(1,node_it):.1f};  leaf iters/round {leaf_it/rounds:.2f} mean lanes {L[1]/max(1,leaf_it):.1f}")
+    print(f"  per round: shade lanes {L[3]/rounds:.1f} (miss {L[4]/rounds:.1f}), gen lanes {L[5]/rounds:.1f}, begin lanes {L[6]/rounds:.1f}, done lanes {L[7]/rounds:.1f}")
+    print(f"  trav iters per round: {v[11]/max(1,v[10]):.2f}; cycles per trav iter: {v[2]/max(1,v[11]):.1f}; cycles per round: {tot/max(1,v[10]):.1f}")
