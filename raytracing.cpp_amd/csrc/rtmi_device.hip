@@ -18,7 +18,7 @@
 //    encoded material handles kept in LDS, so the colour is bit-identical to the recursion.
 //  * traversal: per iteration the wave votes between a node step and a leaf step; it leaves the loop as soon as
 //    enough lanes wait for shading (ballot/popcount), shades them, refills them and re-enters traversal.
-//  * rejection sampling of random_unit_vector is done by the whole wave together (coop_unit_vector).
+//  * rejection sampling of random_unit_vector is done by the whole wave together (coop_draws).
 //  * paths that turn out to bounce inside an opaque sphere are deferred to a compacted queue and finished by a
 //    second launch (DRAIN variant) whose lanes all walk such paths.
 //  * scene (BVH nodes, spheres, materials) staged once per workgroup into LDS with coalesced 16-byte loads; the
@@ -184,68 +184,78 @@ DEV Blk rng_block(const Rng& r, uint32_t blk, uint64_t seed) {
     philox4x32_10(blk, r.sample, r.pixel, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), b);
     return b;
 }
-DEV uint32_t rng_u32(Rng& r, uint64_t seed) { // one draw at the current position
-    const uint32_t k = r.k++;
-    const Blk b = rng_block(r, k >> 2, seed);
-    const uint32_t j = k & 3u;
-    return j == 0u ? b.w0 : (j == 1u ? b.w1 : (j == 2u ? b.w2 : b.w3));
-}
 // (float)(random_double() - 0.5f)   [sample_square, random.number.gen.hpp:16]:  (u - 2^31) * 2^-32, exact in double
 DEV float draw_centered(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 2.3283064365386963e-10f; }
 // (float)random_double(-1, 1)       [random.number.gen.hpp:12-14]:  -1 + 2u*2^-32 = (u - 2^31) * 2^-31, exact in double
+DEV float draw_pm1(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 4.6566128730773926e-10f; }
+
 // wave-wide vote straight from the compare (HIP's __ballot goes through an int and a second compare)
 DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-DEV float draw_pm1(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 4.6566128730773926e-10f; }
+// The wave's draw service for the shading step.  Every draw is a pure function of (seed, pixel, sample, k), so any
+// lane can evaluate any Philox block of any other lane's stream; once per round each shading lane files one request
+// and the whole wave works them off, 64 blocks per pass:
+//   RQ_UNIT  random_unit_vector (random.number.gen.hpp:21-29; `> 1e-160` on a float is `> 0`).  A per-lane rejection
+//            loop costs the wave its longest run of rejections (6.6 passes for 1.9 attempts per lane at 52 %
+//            acceptance).  Every attempt takes one whole block (it starts at a block boundary and skips the fourth
+//            word), and each pass spreads the lanes still without a vector over all 64 lanes -- pass 1: one attempt
+//            each; pass 2: two attempts for each of the ~27 lanes left; pass 3: ~10 each.  Returns the vector.
+//   RQ_WORD  the raw draw at the current position (the dielectric's reflectance test, material.defs.cc:71): rides
+//            along in the first pass instead of costing the wave a Philox evaluation of its own at the occupancy of
+//            the dielectric branch.  Returns the bits in .x; the caller advances k if it consumes the draw.
+// `tbl` is 64 bytes of LDS private to the wave.
+enum : uint32_t { RQ_NONE = 0, RQ_UNIT = 1, RQ_WORD = 2 };
 
-// random_unit_vector, random.number.gen.hpp:21-29 (`> 1e-160` on a float is `> 0`), in cooperative form: called by
-// ALL lanes of a wave.  A rejection loop costs the wave its longest run
-// of rejections (6.6 passes for 1.9 attempts per lane at 52 % acceptance).  The draws are counter based, so any lane
-// can evaluate any attempt of any other lane's stream: every attempt takes one whole Philox block (it starts at a
-// block boundary and skips the fourth word), and each pass spreads the lanes still without a vector over all 64
-// lanes -- pass 1: one attempt each; pass 2: two attempts for each of the ~27 lanes left; pass 3: ~10 each.
-// `tbl` is 64 bytes of LDS private to the wave.  Returns the vector (unused where !need).
-DEV V3 coop_unit_vector(bool need, Rng& rng, uint64_t seed, volatile uint8_t* tbl) {
+DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, volatile uint8_t* tbl) {
     V3 out = mk(0.0f, 0.0f, 0.0f);
-    if (need) rng.k = (rng.k + 3u) & ~3u; // attempts are block aligned
+    if (code == RQ_UNIT) rng.k = (rng.k + 3u) & ~3u; // attempts are block aligned
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    uint64_t todo = ballot(need);
-    bool pending = need;
+    const uint32_t word_sel = code == RQ_WORD ? 4u + (rng.k & 3u) : 0u; // bit 2: a word request
+    bool pending = code != RQ_NONE;
+    uint64_t todo = ballot(pending);
     while (todo != 0ull) {
         const uint32_t n = (uint32_t)__popcll(todo);
         const uint32_t per = min(64u / n, 8u); // attempts per pending lane in this pass
         const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
         if (pending) tbl[my_rank] = (uint8_t)lane; // rank -> lane of the pending stream
         // this lane evaluates attempt `a` of the pending lane of rank `r`
-        const uint32_t a = (uint32_t)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)n));
+        const float inv_n = __builtin_amdgcn_rcpf((float)n);
+        const uint32_t a = (uint32_t)(((float)lane + 0.5f) * inv_n);
         const uint32_t r = lane - a * n;
         const bool helper = a < per;
         const uint32_t src = tbl[r];
         const uint32_t pix = (uint32_t)__shfl((int)rng.pixel, (int)src);
-        const uint32_t smp = (uint32_t)__shfl((int)rng.sample, (int)src);
+        const uint32_t smp = (uint32_t)__shfl((int)(rng.sample | (word_sel << 16)), (int)src);
         const uint32_t kb = (uint32_t)__shfl((int)rng.k, (int)src);
         bool ok = false;
         V3 u = mk(0.0f, 0.0f, 0.0f); // the accepted point, not yet normalised
         if (helper) {
             Blk tmp;
-            philox4x32_10((kb >> 2) + a, smp, pix, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), tmp);
-            u = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
-            const float l2 = vdot(u, u);
-            ok = l2 > 0.0f && l2 <= 1.0f; // random.number.gen.hpp:25-27
+            philox4x32_10((kb >> 2) + a, smp & 0xffffu, pix, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), tmp);
+            if (smp & 0x40000u) { // word request: word (k & 3) of block k >> 2
+                const uint32_t j = (smp >> 16) & 3u;
+                u.x = __uint_as_float(j == 0u ? tmp.w0 : (j == 1u ? tmp.w1 : (j == 2u ? tmp.w2 : tmp.w3)));
+                ok = a == 0u;
+            } else {
+                u = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
+                const float l2 = vdot(u, u);
+                ok = l2 > 0.0f && l2 <= 1.0f; // random.number.gen.hpp:25-27
+            }
         }
         const uint64_t okm = ballot(ok);
-        // the pending lane takes its first accepted attempt, in attempt order
-        uint32_t first = per;
-#pragma unroll
-        for (uint32_t c = 8u; c-- > 0u;) {
-            if (c < per && ((okm >> (my_rank + c * n)) & 1ull)) first = c;
-        }
-        const bool found = pending && first < per;
-        const uint32_t from = found ? my_rank + first * n : lane;
+        // the pending lane takes its first accepted attempt, in attempt order: its attempts sit at bits
+        // my_rank + c * n (c < per) of the vote
+        uint64_t stride_mask = 0ull;
+        for (uint32_t c = 0; c < per; ++c) stride_mask |= 1ull << (c * n); // wave-uniform
+        const uint64_t hits = (okm >> my_rank) & stride_mask;
+        const bool found = pending && hits != 0ull;
+        const uint32_t pos = (uint32_t)__builtin_ctzll(hits | (1ull << 63));
+        const uint32_t first = (uint32_t)(((float)pos + 0.5f) * inv_n);
+        const uint32_t from = found ? my_rank + pos : lane;
         const float ux = __shfl(u.x, (int)from), uy = __shfl(u.y, (int)from), uz = __shfl(u.z, (int)from);
         if (found) {
             out = mk(ux, uy, uz);
-            rng.k += 4u * (first + 1u);
+            if (code == RQ_UNIT) rng.k += 4u * (first + 1u);
             pending = false;
         } else if (pending) {
             rng.k += 4u * per;
@@ -253,7 +263,7 @@ DEV V3 coop_unit_vector(bool need, Rng& rng, uint64_t seed, volatile uint8_t* tb
         todo = ballot(pending);
     }
     // p / sqrt(dot(p, p)) once, on the owner's lane: the IEEE square root and divisions are not paid per attempt
-    if (need) out = vdivs(out, __builtin_sqrtf(vdot(out, out)));
+    if (code == RQ_UNIT) out = vdivs(out, __builtin_sqrtf(vdot(out, out)));
     return out;
 }
 
@@ -332,7 +342,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
     // counter word saturates at ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M
     // work items and 35 M deferred paths)
     uint32_t* pool = reinterpret_cast<uint32_t*>(lds_raw + P.lds_pool) + (threadIdx.x >> 6) * 20u;
-    volatile uint8_t* rank_tbl = reinterpret_cast<volatile uint8_t*>(pool + 4); // 64 bytes, see coop_unit_vector
+    volatile uint8_t* rank_tbl = reinterpret_cast<volatile uint8_t*>(pool + 4); // 64 bytes, see coop_draws
     if ((threadIdx.x & 63u) == 0u) {
         pool[0] = 0u; pool[1] = 0u; pool[2] = 0u; pool[3] = 0u;
     }
@@ -690,10 +700,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
         PF_LANES(pl7, ballot(phase == PH_DONE));
         // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
         // unit vectors for every Lambertian / Metallic hit of this round, generated by the whole wave together
-        bool need_unit = false;
-        if (phase == PH_SHADE && t.cur != 0xfffffffeu && t.best != ~0u) need_unit = lds_aux[t.best].w != 2u;
+        uint32_t rq = RQ_NONE; // Lambertian / Metallic hit: a unit vector; Dielectric hit: one draw
+        if (phase == PH_SHADE && t.cur != 0xfffffffeu && t.best != ~0u) rq = lds_aux[t.best].w != 2u ? RQ_UNIT : RQ_WORD;
         PF_MARK(pf8);
-        const V3 unit_vec = coop_unit_vector(need_unit, rng, P.seed, rank_tbl);
+        const V3 unit_vec = coop_draws(rq, rng, P.seed, rank_tbl);
         PF_MARK(pf5);
         if (phase == PH_SHADE) {
             bool ended = false;
@@ -744,7 +754,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                         const double x2 = xd * xd;
                         const float p5 = (float)((x2 * x2) * xd);
                         const float schlick = r1 + (1.0f - r1) * p5;
-                        const double u = (double)rng_u32(rng, P.seed) * 2.3283064365386963e-10;
+                        const double u = (double)__float_as_uint(unit_vec.x) * 2.3283064365386963e-10; // the draw at rng.k
+                        rng.k++;
                         reflect_it = (double)schlick > u;
                     }
                     sd = reflect_it ? vreflect(unit_dir, N) : vrefract(unit_dir, N, eta);
@@ -1315,7 +1326,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     s->lds_att = off;
     if (!s->big) off += kAttLds * s->block * 4u;
     s->lds_pool = off; // per wave: {work_next, work_end, slot_next, slot_end}
-    off += (s->block / 64u) * 80u; // + 64-byte rank table of coop_unit_vector
+    off += (s->block / 64u) * 80u; // + 64-byte rank table of coop_draws
     s->lds_bytes = align16(off);
     if (s->lds_bytes > 160u * 1024u) {
         set_error("rtmi_scene_create: traversal stack does not fit the 160 KiB LDS of a CU (BVH too deep)");
