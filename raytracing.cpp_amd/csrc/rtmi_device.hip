@@ -1102,14 +1102,16 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     P.n_chunks = 1;
     P.sample_buf = nullptr;
     const size_t sample_floats = (size_t)n_local_rows * W * spp; // float4 records
-    // chunk size: aim at ~64 work items per lane of the persistent grid (A/B on MI355X at 1080p x 512 spp: 64-sample
-    // chunks 422 ms, 32: 430, 128: 433, 16: 489, whole pixels 554), never below 16 samples
+    // chunk size: aim at ~128 work items per lane of the persistent grid, never below 4 samples.  The end of a launch is
+    // a tail of lanes finishing their last item while the others idle, so items must be short next to the launch
+    // (A/B on MI355X, 1080p x 512 spp, ms per launch: whole frame 4: 223.1, 8: 219.1, 16: 217.8, 24: 217.6, 32: 219.0,
+    // 86: 235.4; the eighth of the frame one of 8 GPUs renders 2: 32.2, 4: 31.4, 8: 32.6, 16: 36.2, 32: 42.8)
     uint32_t chunk = s->chunk;
     if (chunk == ~0u) {
-        const uint64_t want_items = 64ull * s->grid * s->block;
+        const uint64_t want_items = 128ull * s->grid * s->block;
         const uint64_t pixels = (uint64_t)n_local_rows * W;
         const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, (want_items + pixels - 1) / pixels);
-        chunk = std::max(16u, (spp + n_chunks - 1u) / std::max(1u, n_chunks));
+        chunk = std::max(4u, (spp + n_chunks - 1u) / std::max(1u, n_chunks));
     }
     if (chunk && spp > chunk && sample_floats * sizeof(float4) <= s->sample_buf_cap_bytes) {
         if (sample_floats > s->samples_capacity) {

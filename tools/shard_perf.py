@@ -16,7 +16,8 @@ W, H = cam.img_width, cam.img_height
 stream = torch.cuda.current_stream(dev).cuda_stream
 with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
     base = None
-    for G in (1, 2, 4, 8):
+    gs = [int(g) for g in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8]
+    for G in gs:
         plan = pkg.RowShardPlan(H, 8, G)
         worst = 0.0
         per_rank = []
@@ -31,8 +32,9 @@ with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
                 torch.cuda.synchronize(dev)
                 ts.append((time.perf_counter() - t0) * 1e3)
             per_rank.append(min(ts[1:]))
+            kms = sc.last_kernel_ms()
         worst = max(per_rank)
         if base is None:
             base = worst
-        print(f"G={G}: slowest rank {worst:8.2f} ms, fastest {min(per_rank):8.2f} ms, speed-up bound {base / worst:5.2f}x "
+        print(f"G={G}: slowest rank {worst:8.2f} ms (trace kernels of the last rank {kms:7.2f} ms), fastest {min(per_rank):8.2f} ms, speed-up bound {base / worst:5.2f}x "
               f"({100.0 * base / worst / G:5.1f} % of ideal)", flush=True)
