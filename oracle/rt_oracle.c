@@ -492,7 +492,8 @@ static inline float ray_pad(const scene_t* sc, const ray_t* r) {
             const float m = fmaxf(d0 * d0, d1 * d1);
             far2 = far2 + m;
         }
-        const float ec = (sc->pad_eps * far2) * k[6];
+        const float x = sc->pad_eps * far2; /* sqrt(R^2 + x) - R <= min(x / (2R), sqrt(x)) */
+        const float ec = fminf(x * k[6], sqrtf(x) * 1.000001f);
         e = fmaxf(e, ec);
     }
     return e;

@@ -444,7 +444,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                 const float ax = fmaxf((o.x - k[0]) * (o.x - k[0]), (k[3] - o.x) * (k[3] - o.x));
                 const float ay = fmaxf((o.y - k[1]) * (o.y - k[1]), (k[4] - o.y) * (k[4] - o.y));
                 const float az = fmaxf((o.z - k[2]) * (o.z - k[2]), (k[5] - o.z) * (k[5] - o.z));
-                pad = fmaxf(pad, (P.pad_eps * ((ax + ay) + az)) * k[6]);
+                // sqrt(R^2 + x) - R <= min(x / (2R), sqrt(x)): the linear bound explodes for a ray that starts thousands of
+                // units away (a path inside the ground sphere), the square root does not
+                const float x = P.pad_eps * ((ax + ay) + az);
+                pad = fmaxf(pad, fminf(x * k[6], __builtin_amdgcn_sqrtf(x) * 1.000001f));
             }
             t.oinv = mk(-(o.x * t.inv.x), -(o.y * t.inv.y), -(o.z * t.inv.z));
             t.pinv = mk(pad * __builtin_fabsf(t.inv.x), pad * __builtin_fabsf(t.inv.y), pad * __builtin_fabsf(t.inv.z));
