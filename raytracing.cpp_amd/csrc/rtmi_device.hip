@@ -599,8 +599,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                 const uint64_t m_node = m_trav & ~m_leaf;
                 if (m_trav == 0ull) break;
                 PF_COUNT(pf11);
+#ifdef RTMI_PROF
                 if (__popcll(m_leaf) > __popcll(m_node)) { PF_COUNT(pl0); PF_LANES(pl1, m_leaf); } else { PF_LANES(pl2, m_node); }
-                const int n_leaf = (int)__popcll(m_leaf), n_node = (int)__popcll(m_node);
+#endif
+                int n_leaf = (int)__popcll(m_leaf), n_node = (int)__popcll(m_node);
+                // keep the counts 32-bit scalars: left alone the compiler compares the 64-bit popcounts, for which
+                // the scalar unit has no greater-than, and moves the vote's outcome through the vector unit
+                asm volatile("" : "+s"(n_leaf), "+s"(n_node));
                 if (n_leaf + n_node <= trav_floor) break;
                 bool pop = false;
                 if (n_leaf > n_node) {
