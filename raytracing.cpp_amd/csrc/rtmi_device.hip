@@ -654,16 +654,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                     const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
                     const uint32_t ch0 = n3.x, ch1 = n3.y;
                     asm volatile("" ::"v"(ch0), "v"(ch1)); // keep the child-reference read with the box reads (one LDS round trip)
-                    if (hit0 || hit1) {
-                        const bool take1 = hit1 && (!hit0 || tn1 < tn0); // nearer child first
-                        if (hit0 && hit1) {
-                            *reinterpret_cast<StackT*>(lds_raw + t.sp) = (StackT)(take1 ? ch0 : ch1);
-                            t.sp += sp_stride;
-                        }
-                        t.cur = take1 ? ch1 : ch0;
-                    } else {
-                        pop = true;
+                    // flat on purpose: selects instead of nested branches (each nesting level is an exec-mask
+                    // save / restore and a branch of the wave)
+                    const bool nearer1 = tn1 < tn0;
+                    const bool take1 = hit1 & (!hit0 | nearer1); // nearer child first (bitwise: no short-circuit branches)
+                    if (hit0 & hit1) {
+                        *reinterpret_cast<StackT*>(lds_raw + t.sp) = (StackT)(take1 ? ch0 : ch1);
+                        t.sp += sp_stride;
                     }
+                    t.cur = take1 ? ch1 : ch0; // overwritten by the pop when neither box is hit
+                    pop = !(hit0 | hit1);
                 }
                 if (pop) {
                     t.sp -= sp_stride;
