@@ -612,15 +612,21 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                     if (phase == PH_TRAV && at_leaf) {
                         const uint32_t first = BIG ? (t.cur & 0x00ffffffu) : (t.cur & 0x1fffu);
                         const uint32_t cnt = BIG ? ((t.cur >> 24) & 0x7fu) : (((t.cur >> 13) & 3u) + 1u);
-                        for (uint32_t q = 0; q < cnt; q += 2u) { // two spheres per trip: both discriminants, then the roots
+                        // two spheres at a time: both discriminants, then the (rare) roots.  The first pair is straight
+                        // code -- with the default leaf size of 2 it is the whole leaf -- larger leaves loop on
+                        auto pair = [&](uint32_t q) {
                             const bool two = q + 1u < cnt;
                             const uint4 r0 = lds_spheres[first + q];
-                            const uint4 r1 = lds_spheres[first + (two ? q + 1u : q)];
+                            const uint4 r1 = lds_spheres[first + q + (two ? 1u : 0u)];
                             float h0, h1, d0, d1;
                             sphere_delta(r0, t, h0, d0);
                             sphere_delta(r1, t, h1, d1);
                             if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, first + q, lds_aux, t.tbest, t.best);
-                            if (two && d1 >= 0.0f) sphere_root_bvh(h1, d1, t, first + q + 1u, lds_aux, t.tbest, t.best);
+                            if (two & (d1 >= 0.0f)) sphere_root_bvh(h1, d1, t, first + q + 1u, lds_aux, t.tbest, t.best);
+                        };
+                        pair(0u);
+                        if (cnt > 2u) {
+                            for (uint32_t q = 2u; q < cnt; q += 2u) pair(q);
                         }
                         if (STATS) st_sphere += cnt;
                         pop = true;
