@@ -1055,8 +1055,10 @@ void free_scene(rtmi_scene* s) {
     delete s;
 }
 
-int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks,
-           uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream) {
+// one launch sequence (primary + drain + resolve) over a set of row blocks; `first` / `last`: position within a banded
+// call (the events of rtmi_scene_last_kernel_ms bracket the whole call)
+int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks,
+               uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream, bool first, bool last) {
     const uint32_t H = s->cam.img_height, W = s->cam.img_width;
     if (block_rows == 0 || block_stride == 0) {
         set_error("rtmi: block_rows and block_stride must be positive");
@@ -1183,7 +1185,7 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     P.stats = s->d_stats;
 
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, 4 * sizeof(uint32_t), stream));
-    HIP_TRY(hipEventRecord(s->ev0, stream));
+    if (first) HIP_TRY(hipEventRecord(s->ev0, stream));
     KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big);
     void* args[] = {&P};
     HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
@@ -1196,16 +1198,62 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
         HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(pick_drain_kernel(s->collect_stats)), dim3(s->grid),
                                 dim3(s->block), dargs, s->lds_bytes, stream));
     }
-    HIP_TRY(hipEventRecord(s->ev2, stream));
+    if (first && last) HIP_TRY(hipEventRecord(s->ev2, stream));
     if (P.sample_buf) {
         const uint32_t n_pixels = n_local_rows * W;
         hipLaunchKernelGGL(rtmi_resolve_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, P.sample_buf,
                            n_pixels, spp, s->cam.pixels_sample_scale, d_rgb, d_rgba);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(s->ev1, stream));
-    s->ev_valid = true;
+    if (last) {
+        if (!first) HIP_TRY(hipEventRecord(s->ev2, stream)); // banded call: trace and resolve launches interleave
+        HIP_TRY(hipEventRecord(s->ev1, stream));
+        s->ev_valid = true;
+    }
     return RTMI_OK;
+}
+
+// The sample records of a launch (16 B per sample) must fit the buffer cap; a frame that does not fit is rendered in
+// bands of rows, one launch sequence each, rather than falling back to whole-pixel work items (config 5:
+// 800 x 800 x 4096 spp = 42 GB of records, two bands).  The draw streams are keyed by the absolute pixel, so banding
+// does not change a bit of the image.
+int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks,
+           uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream) {
+    const uint32_t H = s->cam.img_height, W = s->cam.img_width;
+    const uint64_t row_bytes = (uint64_t)W * s->cam.samples_per_pixel * sizeof(float4);
+    const uint64_t cap = s->sample_buf_cap_bytes;
+    const uint64_t max_rows = row_bytes ? cap / row_bytes : 0;
+    const bool split_on = s->chunk != 0u && s->cam.samples_per_pixel > 4u;
+    if (split_on && max_rows >= 1 && block_rows != 0 && block_stride != 0 && n_blocks != 0 && y_first < H) {
+        if (n_blocks == 1) { // contiguous rows
+            const uint32_t rows = std::min(block_rows, H - y_first);
+            if (rows > max_rows) {
+                const uint32_t n_bands = (uint32_t)((rows + max_rows - 1) / max_rows);
+                const uint32_t band = (rows + n_bands - 1) / n_bands;
+                for (uint32_t r0 = 0; r0 < rows; r0 += band) {
+                    const uint32_t nr = std::min(band, rows - r0);
+                    const int rc = launch_one(s, y_first + r0, nr, 1, 1, seed, d_rgb ? d_rgb + (size_t)r0 * W * 3 : nullptr,
+                                              d_rgba ? d_rgba + (size_t)r0 * W : nullptr, stream, r0 == 0, r0 + nr >= rows);
+                    if (rc != RTMI_OK) return rc;
+                }
+                return RTMI_OK;
+            }
+        } else if ((uint64_t)n_blocks * block_rows > max_rows && block_rows <= max_rows) { // whole blocks per band
+            const uint32_t per_band = (uint32_t)(max_rows / block_rows);
+            const uint32_t n_bands = (n_blocks + per_band - 1) / per_band;
+            const uint32_t per = (n_blocks + n_bands - 1) / n_bands;
+            for (uint32_t b0 = 0; b0 < n_blocks; b0 += per) {
+                const uint32_t nb = std::min(per, n_blocks - b0);
+                const size_t row0 = (size_t)b0 * block_rows;
+                const int rc = launch_one(s, y_first + b0 * block_stride * block_rows, block_rows, block_stride, nb, seed,
+                                          d_rgb ? d_rgb + row0 * W * 3 : nullptr, d_rgba ? d_rgba + row0 * W : nullptr,
+                                          stream, b0 == 0, b0 + nb >= n_blocks);
+                if (rc != RTMI_OK) return rc;
+            }
+            return RTMI_OK;
+        }
+    }
+    return launch_one(s, y_first, block_rows, block_stride, n_blocks, seed, d_rgb, d_rgba, stream, true, true);
 }
 
 } // namespace

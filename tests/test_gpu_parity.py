@@ -304,6 +304,40 @@ def test_device_pointer_entry_and_sharded_blocks(pkg, ob, rtow, gpu):
             assert np.array_equal(frame8, want8)
 
 
+def test_frames_larger_than_the_sample_buffer_are_rendered_in_bands(pkg, ob, rtow, gpu, monkeypatch):
+    """When the sample records of a call exceed RTMI_SAMPLE_BUF_MB the call is split into bands of rows (contiguous
+    rows) or of whole row blocks (sharded call); the draw streams are keyed by the absolute pixel, so the frame is the
+    oracle's, bit for bit, and rtmi_scene_last_kernel_ms brackets all bands."""
+    torch = gpu
+    kw = dict(image_width=128, samples_per_pixel=96, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    W, H = cam.img_width, cam.img_height
+    want, want8 = ob.render_rect_counter(ocam, *rtow, 45, 0, 0, W, H, nthreads=8)
+    monkeypatch.setenv("RTMI_SAMPLE_BUF_MB", "1")  # 196 KB of records per row: 5 rows per band
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH) as s:
+        rgb, rgba = s.render_rows(0, H, 45)
+        assert s.last_kernel_ms() > 0.0
+        part, part8 = s.render_rows(7, 31, 45)  # a row range that is not a multiple of the band
+    _assert_frames_equal(rgb, want)
+    assert np.array_equal(rgba, want8)
+    _assert_frames_equal(part, want[7:31])
+    assert np.array_equal(part8, want8[7:31])
+    monkeypatch.setenv("RTMI_SAMPLE_BUF_MB", "4")  # 21 rows: two 8-row blocks per band
+    dev = torch.device("cuda", 0)
+    with pkg.Scene(cam, *rtow, device=0) as s:
+        plan = pkg.RowShardPlan(H, 8, 2)
+        parts = []
+        for r in range(2):
+            y_first, n_blocks, rows = plan.shard(r)
+            buf = torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev)
+            s.render_row_blocks_device(y_first, 8, 2, n_blocks, 45, buf.data_ptr(), 0,
+                                       torch.cuda.current_stream(dev).cuda_stream)
+            parts.append(buf)
+        torch.cuda.synchronize()
+        frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev)).cpu().numpy()
+    _assert_frames_equal(frame, want)
+
+
 def test_kernel_statistics_match_oracle_counters(pkg, ob, rtow, gpu):
     kw = dict(image_width=96, samples_per_pixel=8, max_depth=50)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))

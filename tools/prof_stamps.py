@@ -12,8 +12,14 @@ if "--build" in sys.argv:
 pkg.LIB_PATH = prof_lib
 os.environ.setdefault("RTMI_WAIT_THRESH", "56")
 w, spp = int(sys.argv[1]), int(sys.argv[2])
-cam = pkg.camera_setup(pkg.camera_params(image_width=w, samples_per_pixel=spp, max_depth=50))
-objs, mats = pkg.make_world_spheres(12345)
+if len(sys.argv) > 3 and sys.argv[3] == "grid":  # BASELINE config 4: 100k spheres, scene in HBM
+    from tests.scenes import big_grid
+    objs, mats, kw = big_grid(316)
+    kw.update(image_width=w, samples_per_pixel=spp)
+    cam = pkg.camera_setup(pkg.camera_params(**kw))
+else:
+    cam = pkg.camera_setup(pkg.camera_params(image_width=w, samples_per_pixel=spp, max_depth=50))
+    objs, mats = pkg.make_world_spheres(12345)
 with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
     sc.render_rows(0, cam.img_height, 7)
     ms = sc.last_kernel_ms()
