@@ -338,6 +338,17 @@ def test_frames_larger_than_the_sample_buffer_are_rendered_in_bands(pkg, ob, rto
     _assert_frames_equal(frame, want)
 
 
+@pytest.mark.parametrize("name", ["thumb_config2", "thumb_config5"])
+def test_regression_thumbnails(pkg, gpu, name):
+    """The stored regression images (tests/golden/thumb_*.png, written by the oracle) against the GPU's RGBA8 output."""
+    from tests.golden.make_thumbnails import SEED, read_png, rgba_to_rgb, thumbs
+    objs, mats, kw = thumbs()[name]
+    cam = pkg.camera_setup(pkg.camera_params(**kw))
+    with pkg.Scene(cam, objs, mats) as s:
+        _, rgba = s.render_rows(0, cam.img_height, SEED)
+    assert np.array_equal(rgba_to_rgb(rgba), read_png(os.path.join(GOLDEN, name + ".png")))
+
+
 def test_kernel_statistics_match_oracle_counters(pkg, ob, rtow, gpu):
     kw = dict(image_width=96, samples_per_pixel=8, max_depth=50)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))

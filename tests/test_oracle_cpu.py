@@ -285,3 +285,13 @@ def test_bvh_walk_equals_linear_scan(ob, pkg, rtow, leaf):
     assert got.tobytes() == lin.tobytes() and got8.tobytes() == lin8.tobytes()
     assert c1["segments"] == c0["segments"] and c0["sphere_tests"] == 488 * c0["segments"]
     assert c1["node_tests"] > 0 and c1["sphere_tests"] < c0["sphere_tests"] // 20
+
+
+@pytest.mark.parametrize("name", ["thumb_config2", "thumb_config5"])
+def test_regression_thumbnails(ob, name):
+    """tests/golden/thumb_*.png (make_thumbnails.py): the oracle's RGBA8 frames of configs 2 and 5 at thumbnail size."""
+    from tests.golden.make_thumbnails import SEED, read_png, rgba_to_rgb, thumbs
+    objs, mats, kw = thumbs()[name]
+    cam = ob.camera_setup(ob.camera_params(**kw))
+    _, rgba = ob.render_rect_counter(cam, objs, mats, SEED, 0, 0, cam.img_width, cam.img_height, nthreads=8)
+    assert np.array_equal(rgba_to_rgb(rgba), read_png(os.path.join(GOLDEN, name + ".png")))
