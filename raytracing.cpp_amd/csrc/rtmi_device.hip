@@ -206,7 +206,9 @@ DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // `tbl` is 64 bytes of LDS private to the wave.
 enum : uint32_t { RQ_NONE = 0, RQ_UNIT = 1, RQ_WORD = 2 };
 
-DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, volatile uint8_t* tbl) {
+// (an LDS-qualified pointer: through a generic one these accesses become flat_* instructions with full waits)
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
     V3 out = mk(0.0f, 0.0f, 0.0f);
     if (code == RQ_UNIT) rng.k = (rng.k + 3u) & ~3u; // attempts are block aligned
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -342,7 +344,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
     // counter word saturates at ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M
     // work items and 35 M deferred paths)
     uint32_t* pool = reinterpret_cast<uint32_t*>(lds_raw + P.lds_pool) + (threadIdx.x >> 6) * 20u;
-    volatile uint8_t* rank_tbl = reinterpret_cast<volatile uint8_t*>(pool + 4); // 64 bytes, see coop_draws
+    lds_u8* rank_tbl = (lds_u8*)(pool + 4); // 64 bytes, see coop_draws
     if ((threadIdx.x & 63u) == 0u) {
         pool[0] = 0u; pool[1] = 0u; pool[2] = 0u; pool[3] = 0u;
     }
