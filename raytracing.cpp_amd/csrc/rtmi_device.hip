@@ -69,7 +69,7 @@ struct RtmiLaunch {
     const uint4* aux;      // [n_slots] {object index, material handle, radius bits, MaterialKind of that handle}
     const uint4* mats;     // [n_mats]  {p0, p1, p2, p3} (albedo + fuzz, or refraction index in p0); the kind rides in aux.w
     const uint4* nodes;    // [n_nodes] 4 x uint4 per node (rtmi_bvh_node)
-    uint32_t n_slots, n_mats, n_nodes, root_ref, n_top_nodes;
+    uint32_t n_slots, n_mats, n_nodes, root_ref;
     float pad_classes[kMaxPadClasses][8];
     uint32_t n_pad_classes;
     float pad_eps, pad_floor;
@@ -352,18 +352,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
     const uint4* lds_aux;
     const uint4* lds_mats;
     const uint4* lds_nodes;
-    const uint4* top_nodes = nullptr; // BIG: the first n_top_nodes nodes (breadth-first numbering) staged into LDS
     if (BIG) {
+        // (staging the top levels of the tree into LDS was measured at 100k spheres: 17.2 ms with 147 nodes staged,
+        // 17.0 ms with none -- they are L2 hits anyway -- and a pointer that may be LDS or global costs flat_* loads)
         lds_spheres = P.spheres;
         lds_aux = P.aux;
         lds_mats = P.mats;
         lds_nodes = P.nodes;
-        if (ACCEL == RTMI_ACCEL_BVH && P.n_top_nodes) {
-            uint4* w_top = reinterpret_cast<uint4*>(lds_raw); // nodes always start the dynamic LDS segment
-            for (uint32_t i = threadIdx.x; i < 4u * P.n_top_nodes; i += blockDim.x) w_top[i] = P.nodes[i];
-            __syncthreads();
-            top_nodes = w_top;
-        }
     } else {
         // ---- stage the scene into LDS: coalesced 16-byte loads, one pass per array -------------------------
         uint4* w_spheres = reinterpret_cast<uint4*>(lds_raw + P.lds_spheres);
@@ -634,8 +629,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                         pop = true;
                     }
                 } else if (phase == PH_TRAV && !at_leaf) {
-                    // config 4: the top levels of the tree are in LDS, the rest is read from L2 / Infinity Cache
-                    const uint4* np = (BIG && t.cur < P.n_top_nodes) ? top_nodes + 4u * t.cur : lds_nodes + 4u * t.cur;
+                    const uint4* np = lds_nodes + 4u * t.cur; // config 4: read through L2 / Infinity Cache
                     const uint4 n0 = np[0];
                     const uint4 n1 = np[1];
                     const uint4 n2 = np[2];
@@ -1010,7 +1004,6 @@ struct rtmi_scene {
     uint32_t lds_att = 0, lds_pool = 0;
     uint32_t drain_wait_thresh = 56;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
-    uint32_t n_top_nodes = 0;  // HBM-resident scenes: nodes staged into LDS (top of the breadth-first numbered tree)
     hipStream_t stream = nullptr; // private stream of the blocking entry point
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -1092,7 +1085,6 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.n_mats = s->n_mats;
     P.n_nodes = (uint32_t)s->bvh.nodes.size();
     P.root_ref = s->root_ref_dev;
-    P.n_top_nodes = s->n_top_nodes;
     std::memcpy(P.pad_classes, s->bvh.pad_classes, sizeof(P.pad_classes));
     P.n_pad_classes = s->bvh.n_pad_classes;
     P.pad_eps = s->bvh.pad_eps;
@@ -1376,15 +1368,6 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
         s->lds_mats = off;
         off += n_materials * 16u;
         off = align16(off);
-    }
-    if (s->big && s->accel == RTMI_ACCEL_BVH) {
-        // two workgroups per CU: 80 KiB each; what the stack, the pools and the chain leave goes to the top of the tree
-        const uint32_t fixed = s->stack_depth * s->block * 4u + (s->block / 64u) * 80u + 256u;
-        const uint32_t budget = fixed < 72u * 1024u ? 72u * 1024u - fixed : 0u;
-        s->n_top_nodes = (uint32_t)std::min<size_t>(s->bvh.nodes.size(), budget / 64u);
-        if (const char* e = std::getenv("RTMI_TOP_NODES")) s->n_top_nodes = (uint32_t)std::min<size_t>(s->bvh.nodes.size(), (size_t)std::max(0, std::atoi(e)));
-        s->lds_nodes = off;
-        off += s->n_top_nodes * 64u;
     }
     s->lds_stack = off;
     off += s->stack_depth * s->block * (s->big ? 4u : 2u);

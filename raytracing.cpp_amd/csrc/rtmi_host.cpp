@@ -438,8 +438,8 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
     out.nodes = std::move(b.nodes);
     out.slot_object = std::move(b.slots);
     out.depth = b.depth;
-    // Breadth-first numbering: the levels every ray walks through come first, so that the kernel variant for scenes
-    // that do not fit LDS can keep the top of the tree there (rtmi_device.hip, `top_nodes`).
+    // Breadth-first numbering: the levels every ray walks through sit next to each other, which keeps them in the
+    // same few cache lines for scenes that are read from HBM (rtmi_device.hip, BIG variant).
     if (!out.nodes.empty() && !(out.root_ref & kLeafBit)) {
         const uint32_t nn = static_cast<uint32_t>(out.nodes.size());
         std::vector<uint32_t> order;
