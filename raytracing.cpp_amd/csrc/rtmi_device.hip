@@ -996,7 +996,7 @@ struct rtmi_scene {
     hipEvent_t ev2 = nullptr;    // end of the trace kernels (ev1 = end of the launch, resolve included)
     uint4* d_defer = nullptr;    // deferred-path queue
     uint32_t defer_cap = 0;
-    bool defer_enabled = true;
+    int defer_mode = 2;        // 0 off, 1 on, 2 auto: on for launches long enough to pay for the second launch
     // launch geometry
     uint32_t block = 768, grid = 0, lds_bytes = 0, stack_depth = 0; // 2 x 768 lanes per CU = 6 waves per SIMD (<= 80 VGPRs)
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
@@ -1146,7 +1146,11 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.defer_count = s->d_counter + 2;
     P.defer_cap = 0;
     P.mode = 0;
-    if (P.sample_buf && s->defer_enabled && !s->big && s->accel == RTMI_ACCEL_BVH && s->cam.maxdepth >= 16) {
+    // A/B on MI355X, 1080p x 512 spp split over N ranks: the drain launch pays off for the whole frame (+2 %), half of
+    // it (+1.8 %) and a quarter (+0.6 %); for an eighth (133 M samples, 340 per lane) its own ramp and tail cost 3 %
+    const bool defer_pays = (uint64_t)n_local_rows * W * spp >= 512ull * s->grid * s->block;
+    if (P.sample_buf && (s->defer_mode == 1 || (s->defer_mode == 2 && defer_pays)) && !s->big &&
+        s->accel == RTMI_ACCEL_BVH && s->cam.maxdepth >= 16) {
         uint64_t want = std::min<uint64_t>((uint64_t)n_local_rows * W * spp / 16u + 65536u, 0x7fffffffull / 5u);
         if (const char* e = std::getenv("RTMI_DEFER_CAP")) want = (uint64_t)std::max(64, std::atoi(e)); // tests: force overflow
         if (want > s->defer_cap) {
@@ -1427,7 +1431,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     if (const char* e = std::getenv("RTMI_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));
     if (const char* e = std::getenv("RTMI_WAIT_THRESH")) s->wait_thresh = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RTMI_CHUNK")) s->chunk = (uint32_t)std::max(0, std::atoi(e)); // 0: split off
-    if (const char* e = std::getenv("RTMI_DEFER")) s->defer_enabled = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RTMI_DEFER")) s->defer_mode = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RTMI_DRAIN_WAIT")) s->drain_wait_thresh = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RTMI_SAMPLE_BUF_MB")) s->sample_buf_cap_bytes = (size_t)std::max(0, std::atoi(e)) << 20;
     s->grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;

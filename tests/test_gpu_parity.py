@@ -56,7 +56,10 @@ def gpu(pkg):
 # ---------------------------------------------------------------------------------------------------------------
 # golden fixtures and oracle parity at oracle-sized problems
 # ---------------------------------------------------------------------------------------------------------------
-def test_golden_rtow_counter_frame(pkg, gpu):
+@pytest.mark.parametrize("defer", ["auto", "1"])  # auto: launches this small keep the deferred-path queue off
+def test_golden_rtow_counter_frame(pkg, gpu, monkeypatch, defer):
+    if defer != "auto":
+        monkeypatch.setenv("RTMI_DEFER", defer)
     g = np.load(os.path.join(GOLDEN, "rtow_counter_128x72x16.npz"))
     sc = np.load(os.path.join(GOLDEN, "rtow_scene_seed12345.npz"))
     cp = json.loads(str(g["camera"]))
@@ -68,8 +71,11 @@ def test_golden_rtow_counter_frame(pkg, gpu):
         assert np.array_equal(rgba, g["rgba"])
 
 
-def test_golden_cornell_deep_bounce(pkg, gpu):
+@pytest.mark.parametrize("defer", ["auto", "1"])
+def test_golden_cornell_deep_bounce(pkg, gpu, monkeypatch, defer):
     """config 5 shape: enclosed box, 200 bounces."""
+    if defer != "auto":
+        monkeypatch.setenv("RTMI_DEFER", defer)
     g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
     cp = json.loads(str(g["camera"]))
     cam = pkg.camera_setup(pkg.camera_params(**cp))
@@ -152,7 +158,7 @@ def test_scheduling_knobs_do_not_change_the_image(pkg, ob, rtow, gpu, monkeypatc
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
     want, want8 = ob.render_rect_counter(ocam, *rtow, 44, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
     for env in (dict(RTMI_CHUNK="0"), dict(RTMI_CHUNK="16", RTMI_DEFER="0"), dict(RTMI_CHUNK="16", RTMI_DEFER="1"),
-                dict(RTMI_CHUNK="32", RTMI_DEFER_CAP="64"), dict(RTMI_CHUNK="40", RTMI_BLOCK="256", RTMI_WAIT_THRESH="20"),
+                dict(RTMI_CHUNK="32", RTMI_DEFER="1", RTMI_DEFER_CAP="64"), dict(RTMI_CHUNK="40", RTMI_BLOCK="256", RTMI_WAIT_THRESH="20"),
                 dict(RTMI_BLOCKS_PER_CU="1", RTMI_WAIT_THRESH="64", RTMI_TOPDOWN="1")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)

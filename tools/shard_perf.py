@@ -18,7 +18,8 @@ with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
     base = None
     gs = [int(g) for g in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8]
     for G in gs:
-        plan = pkg.RowShardPlan(H, 8, G)
+        BR = int(os.environ.get("SHARD_BLOCK_ROWS", "8"))
+        plan = pkg.RowShardPlan(H, BR, G)
         worst = 0.0
         per_rank = []
         for r in range(G):
@@ -28,7 +29,7 @@ with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
             for it in range(3):
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                sc.render_row_blocks_device(y_first, 8, G, n_blocks, 7, rgb.data_ptr(), 0, stream)
+                sc.render_row_blocks_device(y_first, BR, G, n_blocks, 7, rgb.data_ptr(), 0, stream)
                 torch.cuda.synchronize(dev)
                 ts.append((time.perf_counter() - t0) * 1e3)
             per_rank.append(min(ts[1:]))
