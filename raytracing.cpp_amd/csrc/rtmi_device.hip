@@ -20,9 +20,9 @@
 //    enough lanes wait for shading (ballot/popcount), shades them, refills them and re-enters traversal.
 //  * rejection sampling of random_unit_vector is done by the whole wave together (coop_draws).
 //  * paths that turn out to bounce inside an opaque sphere are deferred to a compacted queue and finished by a
-//    second launch (DRAIN variant) whose lanes all walk such paths.
+//    second launch (DRAIN variant) whose lanes all walk such paths -- for launches long enough to pay for it.
 //  * scene (BVH nodes, spheres, materials) staged once per workgroup into LDS with coalesced 16-byte loads; the
-//    per-lane traversal stack lives in LDS too.  Scenes that do not fit stay in HBM (BIG variant), top of the tree in LDS.
+//    per-lane traversal stack lives in LDS too.  Scenes that do not fit stay in HBM (BIG variant) behind L2 / Infinity Cache.
 //  * counter RNG: Philox4x32-10 keyed by seed, counter (draw block, sample, pixel): the image does not depend on
 //    tiling, row sharding or GPU count.
 //  * arithmetic of the reference path is kept operation for operation (no FMA contraction, IEEE sqrt/div); only the
