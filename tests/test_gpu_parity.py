@@ -263,6 +263,47 @@ def test_row_ranges_outputs_and_errors(pkg, ob, rtow, gpu):
     assert e.value.code == pkg.RTMI_ERR_BAD_ARG
 
 
+def test_ragged_image_sizes_chunks_and_block_strides(pkg, ob, gpu, monkeypatch):
+    """The work-item decode (tile, chunk, pixel, row block: multiply-shift divisions) over awkward geometries: widths and
+    heights that are not multiples of the 8x8 tile, sample counts around the chunk size, strided row blocks."""
+    torch = gpu
+    dev = torch.device("cuda", 0)
+    objs, mats = three_spheres()
+    rng = np.random.default_rng(99)
+    for case in range(36):
+        w = int(rng.choice([1, 2, 7, 8, 9, 15, 17, 31, 33, 63, 65, 100]))
+        aspect = float(rng.choice([0.5, 1.0, 16.0 / 9.0, 3.0]))
+        spp = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 33]))
+        chunk = str(int(rng.choice([0, 1, 2, 3, 4, 5, 8])))
+        depth = int(rng.integers(0, 9))
+        if int(w / aspect) < 1:
+            continue
+        kw = dict(three_spheres_camera(), image_width=w, aspect_ratio=aspect, samples_per_pixel=spp, max_depth=depth)
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        W, H = cam.img_width, cam.img_height
+        want, want8 = ob.render_rect_counter(ocam, objs, mats, case, 0, 0, W, H)
+        monkeypatch.setenv("RTMI_CHUNK", chunk)
+        monkeypatch.setenv("RTMI_DEFER", str(case & 1))
+        with pkg.Scene(cam, objs, mats) as s:
+            rgb, rgba = s.render_rows(0, H, case)
+            _assert_frames_equal(rgb, want)
+            assert np.array_equal(rgba, want8), (w, H, spp, chunk)
+            block = int(rng.choice([1, 2, 3, 8]))
+            world = int(rng.integers(1, 4))
+            plan = pkg.RowShardPlan(H, block, world)
+            parts = []
+            for r in range(world):
+                y_first, n_blocks, rows = plan.shard(r)
+                buf = torch.zeros((max(1, plan.max_rows), W, 3), dtype=torch.float32, device=dev)
+                if n_blocks:
+                    s.render_row_blocks_device(y_first, block, world, n_blocks, case, buf.data_ptr(), 0,
+                                               torch.cuda.current_stream(dev).cuda_stream)
+                parts.append(buf[:plan.max_rows])
+            torch.cuda.synchronize()
+            frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev)).cpu().numpy()
+            _assert_frames_equal(frame, want)
+
+
 def test_concurrent_calls_on_one_scene(pkg, ob, rtow, gpu):
     """rtmi_render_rows may be called from several host threads on one scene (main.cc:608-611: N workers, one core)."""
     kw = dict(image_width=64, samples_per_pixel=4, max_depth=10)
