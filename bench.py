@@ -204,7 +204,7 @@ def main():
         kernel_s = float(kmax.item()) / 1e3
         samples_per_launch = samples / world
         achieved = samples_per_launch * fps / kernel_s / 1e12
-        traffic = None
+        traffic, traffic_note = None, None
         tpath = os.path.join(_ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -212,11 +212,14 @@ def main():
                 if (tj.get("width") == args.width and tj.get("spp") == args.spp and tj.get("n_gpus") == world
                         and args.accel == "bvh"):
                     traffic = tj.get("bytes_per_launch")
+                    traffic_note = ("2*FETCH_SIZE + WRITE_SIZE of the trace launches (profiles/hbm_traffic.json); WRITE_SIZE "
+                                    "tallies 64 B per write request: calibrated on this store pattern it reads 1.91x the "
+                                    "bytes of the 32-byte sample-record pairs (tools/ubench/write_size_calib.hip)")
             except Exception:
                 traffic = None
         out["roofline"] = {
             "bound": "valu", "achieved": round(achieved, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+            "frac": round(achieved / VALU_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_note": traffic_note,
             "kernel": "rtmi_trace_kernel<%s>" % args.accel, "kernel_ms": round(kernel_s * 1e3, 3),
             "flops_per_sample": round(fps, 1),
             "counters_per_sample": {k: round(ctr[k] / ctr["samples"], 3) for k in ctr if k != "samples"},
