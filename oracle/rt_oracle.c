@@ -515,6 +515,29 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
     uint32_t stack[64];
     int sp = 0;
     uint32_t cur = (sc->n_nodes == 0) ? (0x80000000u | (sc->n_slots << 24)) : 0u;
+    /* as the kernel does: a leaf hanging directly off the root (the ground sphere) is tested at segment set-up and */
+    /* the walk starts at the root's other child, without the root's two box tests                                   */
+    uint32_t pre_leaf = 0;
+    if (sc->n_nodes != 0) {
+        const uint32_t c0 = sc->nodes[0].child[0], c1 = sc->nodes[0].child[1];
+        const int l0 = (c0 & 0x80000000u) != 0, l1 = (c1 & 0x80000000u) != 0;
+        if (l0 != l1) {
+            pre_leaf = l0 ? c0 : c1;
+            cur = l0 ? c1 : c0;
+        }
+    }
+    if (pre_leaf) {
+        const uint32_t first = pre_leaf & 0x00ffffffu, count = (pre_leaf >> 24) & 0x7fu;
+        for (uint32_t s = 0; s < count; ++s) {
+            const uint32_t oi = sc->slots[first + s];
+            const float cand = sphere_candidate(&sc->objs[oi], r, tmin);
+            if (ctr) ctr->sphere_tests++;
+            if (cand > tmin && (cand < best_t || (cand == best_t && oi < best))) {
+                best_t = cand;
+                best = oi;
+            }
+        }
+    }
     for (;;) {
         if (cur & 0x80000000u) {
             const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;

@@ -70,6 +70,7 @@ struct RtmiLaunch {
     const uint4* mats;     // [n_mats]  {p0, p1, p2, p3} (albedo + fuzz, or refraction index in p0); the kind rides in aux.w
     const uint4* nodes;    // [n_nodes] 4 x uint4 per node (rtmi_bvh_node)
     uint32_t n_slots, n_mats, n_nodes, root_ref;
+    uint32_t pre_leaf;        // leaf hanging off the root (the ground sphere): tested at segment set-up; 0 = none
     float pad_classes[kMaxPadClasses][8];
     uint32_t n_pad_classes;
     float pad_eps, pad_floor;
@@ -425,6 +426,27 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
         return color;
     };
     const uint32_t sp1 = sp0 + sp_stride;
+    // the spheres of one leaf against the current segment, two at a time: both discriminants, then the (rare) roots.
+    // The first pair is straight code -- with the default leaf size of 2 it is the whole leaf -- larger leaves loop on
+    auto test_leaf = [&](uint32_t ref) {
+        const uint32_t first = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
+        const uint32_t cnt = BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u);
+        auto pair = [&](uint32_t q) {
+            const bool two = q + 1u < cnt;
+            const uint4 r0 = lds_spheres[first + q];
+            const uint4 r1 = lds_spheres[first + q + (two ? 1u : 0u)];
+            float h0, h1, d0, d1;
+            sphere_delta(r0, t, h0, d0);
+            sphere_delta(r1, t, h1, d1);
+            if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, first + q, lds_aux, t.tbest, t.best);
+            if (two & (d1 >= 0.0f)) sphere_root_bvh(h1, d1, t, first + q + 1u, lds_aux, t.tbest, t.best);
+        };
+        pair(0u);
+        if (cnt > 2u) {
+            for (uint32_t q = 2u; q < cnt; q += 2u) pair(q);
+        }
+        if (STATS) st_sphere += cnt;
+    };
     auto begin_segment = [&](V3 o, V3 d) {
         t.o = o;
         t.d = d;
@@ -448,6 +470,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
             }
             t.oinv = mk(-(o.x * t.inv.x), -(o.y * t.inv.y), -(o.z * t.inv.z));
             t.pinv = mk(pad * __builtin_fabsf(t.inv.x), pad * __builtin_fabsf(t.inv.y), pad * __builtin_fabsf(t.inv.z));
+            // A leaf that hangs directly off the root -- the ground sphere, whose box is the whole scene -- is tested
+            // here, by all the lanes that start a segment, and the walk begins at the root's other child with the far
+            // limit already set: one node trip and one leaf trip less for every segment.
+            if (P.pre_leaf != 0u) test_leaf(P.pre_leaf);
         } else {
             t.cur = 0; // next sphere of the linear scan
         }
@@ -610,25 +636,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                 bool pop = false;
                 if (n_leaf > n_node) {
                     if (phase == PH_TRAV && at_leaf) {
-                        const uint32_t first = BIG ? (t.cur & 0x00ffffffu) : (t.cur & 0x1fffu);
-                        const uint32_t cnt = BIG ? ((t.cur >> 24) & 0x7fu) : (((t.cur >> 13) & 3u) + 1u);
-                        // two spheres at a time: both discriminants, then the (rare) roots.  The first pair is straight
-                        // code -- with the default leaf size of 2 it is the whole leaf -- larger leaves loop on
-                        auto pair = [&](uint32_t q) {
-                            const bool two = q + 1u < cnt;
-                            const uint4 r0 = lds_spheres[first + q];
-                            const uint4 r1 = lds_spheres[first + q + (two ? 1u : 0u)];
-                            float h0, h1, d0, d1;
-                            sphere_delta(r0, t, h0, d0);
-                            sphere_delta(r1, t, h1, d1);
-                            if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, first + q, lds_aux, t.tbest, t.best);
-                            if (two & (d1 >= 0.0f)) sphere_root_bvh(h1, d1, t, first + q + 1u, lds_aux, t.tbest, t.best);
-                        };
-                        pair(0u);
-                        if (cnt > 2u) {
-                            for (uint32_t q = 2u; q < cnt; q += 2u) pair(q);
-                        }
-                        if (STATS) st_sphere += cnt;
+                        test_leaf(t.cur);
                         pop = true;
                     }
                 } else if (phase == PH_TRAV && !at_leaf) {
@@ -1008,6 +1016,7 @@ struct rtmi_scene {
     uint32_t lds_att = 0, lds_pool = 0;
     uint32_t drain_wait_thresh = 56;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
+    uint32_t pre_leaf_dev = 0; // leaf child of the root, tested at segment set-up (0 = none)
     hipStream_t stream = nullptr; // private stream of the blocking entry point
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -1089,6 +1098,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.n_mats = s->n_mats;
     P.n_nodes = (uint32_t)s->bvh.nodes.size();
     P.root_ref = s->root_ref_dev;
+    P.pre_leaf = s->pre_leaf_dev;
     std::memcpy(P.pad_classes, s->bvh.pad_classes, sizeof(P.pad_classes));
     P.n_pad_classes = s->bvh.n_pad_classes;
     P.pad_eps = s->bvh.pad_eps;
@@ -1413,6 +1423,16 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
                 nd.child[1] = pack16(nd.child[1]);
             }
             s->root_ref_dev = pack16(s->bvh.root_ref);
+        }
+        // root = (leaf | subtree): hand the leaf to segment set-up and start every walk at the subtree
+        if (s->accel == RTMI_ACCEL_BVH && !dn.empty() && !(s->bvh.root_ref & kLeafBit)) {
+            const rtmi_bvh_node& root = s->bvh.nodes[s->bvh.root_ref];
+            const bool l0 = (root.child[0] & kLeafBit) != 0u, l1 = (root.child[1] & kLeafBit) != 0u;
+            if (l0 != l1) {
+                const uint32_t leaf = l0 ? root.child[0] : root.child[1], other = l0 ? root.child[1] : root.child[0];
+                s->pre_leaf_dev = s->big ? leaf : pack16(leaf);
+                s->root_ref_dev = s->big ? other : pack16(other);
+            }
         }
         HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
     }
