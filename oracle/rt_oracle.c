@@ -515,19 +515,31 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
     uint32_t stack[64];
     int sp = 0;
     uint32_t cur = (sc->n_nodes == 0) ? (0x80000000u | (sc->n_slots << 24)) : 0u;
-    /* as the kernel does: a leaf hanging directly off the root (the ground sphere) is tested at segment set-up and */
-    /* the walk starts at the root's other child, without the root's two box tests                                   */
-    uint32_t pre_leaf = 0;
+    /* as the kernel does: leaves hanging directly off the top of the tree (a spine of (leaf | subtree) nodes, at    */
+    /* most four leaves; the ground sphere) are tested at segment set-up and the walk starts below them, without     */
+    /* the box tests of the peeled nodes                                                                             */
+    uint32_t pre[4];
+    uint32_t n_pre = 0;
+    int no_walk = 0;
     if (sc->n_nodes != 0) {
-        const uint32_t c0 = sc->nodes[0].child[0], c1 = sc->nodes[0].child[1];
-        const int l0 = (c0 & 0x80000000u) != 0, l1 = (c1 & 0x80000000u) != 0;
-        if (l0 != l1) {
-            pre_leaf = l0 ? c0 : c1;
-            cur = l0 ? c1 : c0;
+        uint32_t at = 0;
+        while (!(at & 0x80000000u) && n_pre < 4u) {
+            const uint32_t c0 = sc->nodes[at].child[0], c1 = sc->nodes[at].child[1];
+            const int l0 = (c0 & 0x80000000u) != 0, l1 = (c1 & 0x80000000u) != 0;
+            if (l0 && l1 && n_pre + 2u <= 4u) {
+                pre[n_pre++] = c0;
+                pre[n_pre++] = c1;
+                no_walk = 1;
+                break;
+            }
+            if (l0 == l1) break;
+            pre[n_pre++] = l0 ? c0 : c1;
+            at = l0 ? c1 : c0;
         }
+        if (n_pre) cur = at;
     }
-    if (pre_leaf) {
-        const uint32_t first = pre_leaf & 0x00ffffffu, count = (pre_leaf >> 24) & 0x7fu;
+    for (uint32_t q = 0; q < n_pre; ++q) {
+        const uint32_t first = pre[q] & 0x00ffffffu, count = (pre[q] >> 24) & 0x7fu;
         for (uint32_t s = 0; s < count; ++s) {
             const uint32_t oi = sc->slots[first + s];
             const float cand = sphere_candidate(&sc->objs[oi], r, tmin);
@@ -538,7 +550,7 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
             }
         }
     }
-    for (;;) {
+    for (; !no_walk;) {
         if (cur & 0x80000000u) {
             const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
             for (uint32_t s = 0; s < count; ++s) {

@@ -70,7 +70,8 @@ struct RtmiLaunch {
     const uint4* mats;     // [n_mats]  {p0, p1, p2, p3} (albedo + fuzz, or refraction index in p0); the kind rides in aux.w
     const uint4* nodes;    // [n_nodes] 4 x uint4 per node (rtmi_bvh_node)
     uint32_t n_slots, n_mats, n_nodes, root_ref;
-    uint32_t pre_leaf;        // leaf hanging off the root (the ground sphere): tested at segment set-up; 0 = none
+    uint32_t pre_leaf[4];     // leaves hanging off the top of the tree (the ground sphere): tested at segment set-up
+    uint32_t n_pre_leaves;    // root_ref == kNoWalk: they were the whole tree
     float pad_classes[kMaxPadClasses][8];
     uint32_t n_pad_classes;
     float pad_eps, pad_floor;
@@ -274,6 +275,7 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
 // lane state machine
 // ---------------------------------------------------------------------------------------------------------
 enum : uint32_t { PH_FETCH = 0, PH_GEN = 1, PH_TRAV = 2, PH_SHADE = 3, PH_DONE = 4, PH_BEGIN = 5 };
+constexpr uint32_t kNoWalk = 0xffffffffu; // RtmiLaunch::root_ref: every leaf is tested at segment set-up
 constexpr uint32_t kAttLds = 4; // closed attenuation runs kept in LDS per lane; more material changes spill to HBM
 
 struct Trav { // per-segment traversal state
@@ -470,10 +472,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
             }
             t.oinv = mk(-(o.x * t.inv.x), -(o.y * t.inv.y), -(o.z * t.inv.z));
             t.pinv = mk(pad * __builtin_fabsf(t.inv.x), pad * __builtin_fabsf(t.inv.y), pad * __builtin_fabsf(t.inv.z));
-            // A leaf that hangs directly off the root -- the ground sphere, whose box is the whole scene -- is tested
-            // here, by all the lanes that start a segment, and the walk begins at the root's other child with the far
-            // limit already set: one node trip and one leaf trip less for every segment.
-            if (P.pre_leaf != 0u) test_leaf(P.pre_leaf);
+            // Leaves that hang directly off the top of the tree -- the ground sphere, whose box is the whole scene; the
+            // walls of a box made of huge spheres -- are tested here, by all the lanes that start a segment, and the
+            // walk begins below them with the far limit already set: one node trip and one leaf trip less per leaf
+            // and segment.  A tree that is nothing but such a spine is not walked at all.
+            for (uint32_t q = 0; q < P.n_pre_leaves; ++q) test_leaf(P.pre_leaf[q]);
         } else {
             t.cur = 0; // next sphere of the linear scan
         }
@@ -601,7 +604,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
         if (phase == PH_BEGIN) {
             PF_LANES(pl6, ballot(true));
             begin_segment(t.o, t.d);
-            phase = PH_TRAV;
+            phase = (ACCEL == RTMI_ACCEL_BVH && P.root_ref == kNoWalk) ? PH_SHADE : PH_TRAV;
         }
 
         // waves in the traversal loop issue ahead of waves that shade, draw or fetch: the loop is where the lanes are
@@ -1016,7 +1019,8 @@ struct rtmi_scene {
     uint32_t lds_att = 0, lds_pool = 0;
     uint32_t drain_wait_thresh = 56;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
-    uint32_t pre_leaf_dev = 0; // leaf child of the root, tested at segment set-up (0 = none)
+    uint32_t pre_leaf_dev[4] = {}; // leaves peeled off the top of the tree, tested at segment set-up
+    uint32_t n_pre_leaves = 0;
     hipStream_t stream = nullptr; // private stream of the blocking entry point
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -1098,7 +1102,8 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.n_mats = s->n_mats;
     P.n_nodes = (uint32_t)s->bvh.nodes.size();
     P.root_ref = s->root_ref_dev;
-    P.pre_leaf = s->pre_leaf_dev;
+    std::memcpy(P.pre_leaf, s->pre_leaf_dev, sizeof(P.pre_leaf));
+    P.n_pre_leaves = s->n_pre_leaves;
     std::memcpy(P.pad_classes, s->bvh.pad_classes, sizeof(P.pad_classes));
     P.n_pad_classes = s->bvh.n_pad_classes;
     P.pad_eps = s->bvh.pad_eps;
@@ -1424,15 +1429,25 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
             }
             s->root_ref_dev = pack16(s->bvh.root_ref);
         }
-        // root = (leaf | subtree): hand the leaf to segment set-up and start every walk at the subtree
-        if (s->accel == RTMI_ACCEL_BVH && !dn.empty() && !(s->bvh.root_ref & kLeafBit)) {
-            const rtmi_bvh_node& root = s->bvh.nodes[s->bvh.root_ref];
-            const bool l0 = (root.child[0] & kLeafBit) != 0u, l1 = (root.child[1] & kLeafBit) != 0u;
-            if (l0 != l1) {
-                const uint32_t leaf = l0 ? root.child[0] : root.child[1], other = l0 ? root.child[1] : root.child[0];
-                s->pre_leaf_dev = s->big ? leaf : pack16(leaf);
-                s->root_ref_dev = s->big ? other : pack16(other);
+        // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start
+        // every walk below them
+        if (s->accel == RTMI_ACCEL_BVH && !dn.empty()) {
+            uint32_t cur = s->bvh.root_ref;
+            while (!(cur & kLeafBit) && s->n_pre_leaves < 4u) {
+                const rtmi_bvh_node& nd = s->bvh.nodes[cur];
+                const bool l0 = (nd.child[0] & kLeafBit) != 0u, l1 = (nd.child[1] & kLeafBit) != 0u;
+                if (l0 && l1 && s->n_pre_leaves + 2u <= 4u) { // the spine ends in two leaves: nothing left to walk
+                    s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? nd.child[0] : pack16(nd.child[0]);
+                    s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? nd.child[1] : pack16(nd.child[1]);
+                    cur = kNoWalk;
+                    break;
+                }
+                if (l0 == l1) break;
+                const uint32_t leaf = l0 ? nd.child[0] : nd.child[1];
+                s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? leaf : pack16(leaf);
+                cur = l0 ? nd.child[1] : nd.child[0];
             }
+            if (s->n_pre_leaves) s->root_ref_dev = (cur == kNoWalk) ? kNoWalk : (s->big ? cur : pack16(cur));
         }
         HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
     }
