@@ -416,6 +416,34 @@ def test_kernel_statistics_match_oracle_counters(pkg, ob, rtow, gpu):
     assert st["segments"] == c["segments"] and st["sphere_tests"] == 488 * c["segments"] and st["node_tests"] == 0
 
 
+def test_leaves_peeled_off_the_top_of_the_tree(pkg, ob, gpu):
+    """Scenes whose BVH starts with a spine of (leaf | subtree) nodes -- one to four huge spheres around a cluster, and
+    trees that are nothing but a spine -- are tested at segment set-up instead of being walked; image and counters must
+    still be the oracle's (its walk peels the same leaves)."""
+    lam = (0, (0.6, 0.5, 0.4, 0.0))
+    cluster = [((0.3 * i - 1.0, 0.2, 0.25 * j - 0.5), 0.1, (i % 3, (0.7, 0.6, 0.5, 0.1) if i % 3 != 2 else (1.5, 0.0, 0.0, 0.0)))
+               for i in range(6) for j in range(4)]
+    walls = [((0.0, -1000.0, 0.0), 1000.0, lam), ((0.0, 0.0, -1030.0), 1000.0, lam), ((-1030.0, 0.0, 0.0), 1000.0, lam),
+             ((1030.0, 0.0, 0.0), 1000.0, lam), ((0.0, 1040.0, 0.0), 1000.0, lam)]
+    kw = dict(image_width=96, samples_per_pixel=6, max_depth=20, vertical_fov=40.0, defocus_angle=0.0, focus_distance=5.0,
+              lookfrom=(0.0, 1.0, 6.0), lookat=(0.0, 0.2, 0.0), world_up=(0.0, 1.0, 0.0), aspect_ratio=1.5)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    for n_walls, n_cluster in ((1, 24), (2, 24), (3, 24), (5, 24), (2, 0), (3, 1), (4, 0), (1, 1)):
+        objs, mats = arrays(walls[:n_walls] + cluster[:n_cluster])
+        bvh = pkg.bvh_build(objs)
+        bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
+        want, want8, c = ob.render_rect_counter(ocam, objs, mats, 9, 0, 0, ocam.img_width, ocam.img_height, counters=True,
+                                                bvh=bvh, nthreads=8)
+        with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, collect_stats=True) as s:
+            rgb, rgba = s.render_rows(0, cam.img_height, 9)
+            st = s.stats()
+        _assert_frames_equal(rgb, want)
+        assert np.array_equal(rgba, want8)
+        assert st["segments"] == c["segments"], (n_walls, n_cluster)
+        assert abs(st["sphere_tests"] - c["sphere_tests"]) <= 1e-3 * c["sphere_tests"] + 2
+        assert abs(st["node_tests"] - c["node_tests"]) <= 1e-3 * c["node_tests"] + 2
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE.json's full sizes: size-independent properties
 # ---------------------------------------------------------------------------------------------------------------
