@@ -287,6 +287,27 @@ def test_bvh_walk_equals_linear_scan(ob, pkg, rtow, leaf):
     assert c1["node_tests"] > 0 and c1["sphere_tests"] < c0["sphere_tests"] // 20
 
 
+def test_bvh_walk_with_leaves_peeled_off_the_top_equals_linear_scan(ob, pkg):
+    """The walk tests leaves that hang directly off the top of the tree before it starts (as the kernel does at segment
+    set-up): one to five huge spheres around a cluster, and trees that are only such a spine."""
+    from tests.scenes import arrays
+    lam = (0, (0.6, 0.5, 0.4, 0.0))
+    cluster = [((0.3 * i - 1.0, 0.2, 0.25 * j - 0.5), 0.1, (i % 3, (0.7, 0.6, 0.5, 0.1) if i % 3 != 2 else (1.5, 0.0, 0.0, 0.0)))
+               for i in range(6) for j in range(4)]
+    walls = [((0.0, -1000.0, 0.0), 1000.0, lam), ((0.0, 0.0, -1030.0), 1000.0, lam), ((-1030.0, 0.0, 0.0), 1000.0, lam),
+             ((1030.0, 0.0, 0.0), 1000.0, lam), ((0.0, 1040.0, 0.0), 1000.0, lam)]
+    kw = dict(image_width=64, samples_per_pixel=4, max_depth=20, vertical_fov=40.0, defocus_angle=0.0, focus_distance=5.0,
+              lookfrom=(0.0, 1.0, 6.0), lookat=(0.0, 0.2, 0.0), world_up=(0.0, 1.0, 0.0), aspect_ratio=1.5)
+    cam = ob.camera_setup(ob.camera_params(**kw))
+    for n_walls, n_cluster in ((1, 24), (2, 24), (3, 24), (5, 24), (2, 0), (3, 1), (4, 0), (1, 1)):
+        objs, mats = arrays(walls[:n_walls] + cluster[:n_cluster])
+        lin, lin8, c0 = ob.render_rect_counter(cam, objs, mats, 5, 0, 0, cam.img_width, cam.img_height, counters=True)
+        bvh = pkg.bvh_build(objs)
+        got, got8, c1 = ob.render_rect_counter(cam, objs, mats, 5, 0, 0, cam.img_width, cam.img_height, counters=True, bvh=bvh)
+        assert got.tobytes() == lin.tobytes() and got8.tobytes() == lin8.tobytes(), (n_walls, n_cluster)
+        assert c1["segments"] == c0["segments"] and c1["sphere_tests"] <= c0["sphere_tests"]
+
+
 @pytest.mark.parametrize("name", ["thumb_config2", "thumb_config5"])
 def test_regression_thumbnails(ob, name):
     """tests/golden/thumb_*.png (make_thumbnails.py): the oracle's RGBA8 frames of configs 2 and 5 at thumbnail size."""
