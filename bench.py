@@ -1,34 +1,59 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the path-tracing hot loop on MI355X.
 
-A step = one pass of the hot path over one frame of the S-RTOW workload: the reference's RTOW
-"final scene" generator (488 spheres, seed 12345), 1920x1080, 512 spp, 50 bounces -- the configuration
-BASELINE.json's metric is quoted on.  At N = 1 one GPU renders the whole frame; at N > 1 the image plane is
-sharded by interleaved 8-row blocks, every rank renders its blocks and rank 0 gathers the framebuffer slices with
-one RCCL gather (strong scaling: the frame is fixed).  Scene and BVH are resident in HBM before the timed region;
-the frame stays in HBM (no PCIe in the timed region).
+A step = one pass of the hot path over one frame of a synthetic workload.  Default: BASELINE config 3,
+the configuration the metric is quoted on -- the reference's RTOW "final scene" generator (488 spheres, seed 12345),
+1920x1080, 512 spp, 50 bounces.  `--config 2|4|5` selects the other GPU configs (parity-test cases, measured for
+their own roofline lines).  Scene and BVH are resident in HBM before the timed region and the frame stays in HBM
+(`value`); `value_e2e` adds the D2H copy of the float frame, the definition SURVEY 8(d) gives.
+
+Multi-GPU (strong scaling: the frame is fixed): the image plane is sharded by interleaved 8-row blocks, every rank
+renders its blocks and rank 0 gathers the framebuffer slices with ONE RCCL gather.
+  * `python bench.py --gpus N` with WORLD_SIZE unset: this process only LAUNCHES -- it starts N ranks with
+    torch.distributed.run before anything touches the GPU, relays rank 0's JSON line and exits non-zero if any
+    rank fails.
+  * under torch.distributed.run (WORLD_SIZE set): one rank per GPU, `torch.distributed` backend "nccl" (= RCCL).
+  * `--single-process`: one process drives all N devices through the C-ABI (rtmi_frame_*: ncclCommInitAll +
+    one grouped ncclGather inside librtmi.so).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      algorithmic flops per launch (SURVEY 8d formula, counters from the CPU oracle's instrumented walk
                 of the same BVH) / mean kernel duration from HIP events on the launch stream
   cpu_baseline  the oracle (a port of the reference's CPU path, reference-shaped job system) timed on this host
 """
-import argparse
-import json
 import os
-import sys
-import time
+
+# before anything can initialise HIP/HSA in this process or its children: the pool's host driver only supports dmabuf IPC
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+import socket  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
 
 _ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, _ROOT)
 
-# S-RTOW workload (metric config of BASELINE.json)
-WIDTH, SPP, DEPTH = 1920, 512, 50
 SCENE_SEED, RENDER_SEED = 12345, 2025
 BLOCK_ROWS = 8
 # non-FMA fp32 VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md; its 157.3 TFLOP/s
 # vector peak counts an FMA as 2 flops, which the no-contraction parity bar rules out for the reference arithmetic)
 VALU_PEAK_TFLOPS = 78.6
+
+# BASELINE.json configs[1..4].  lin_*: rows the extra linear-scan (reference algorithm) step renders: block k covers rows
+# [lin_first + k*lin_stride*8, +8); cpu_stride: the CPU baseline renders every n-th pixel in x and y at full spp
+CONFIGS = {
+    "2": dict(scene="rtow", width=1200, spp=100, depth=50, lin=None, cpu_stride=1,
+              name="RTOW book-1 final scene, 1200x675, 100 spp, 50 bounces"),
+    "3": dict(scene="rtow", width=1920, spp=512, depth=50, lin=None, cpu_stride=4,
+              name="RTOW final scene 1920x1080, 512 spp, 50 bounces"),
+    "4": dict(scene="grid", width=1920, spp=256, depth=50, lin=(128, 34, 4), cpu_stride=64,
+              name="100k random spheres with full BVH, 1920x1080, 256 spp"),
+    "5": dict(scene="cornell", width=800, spp=4096, depth=200, lin=(96, 25, 4), cpu_stride=4,
+              name="Cornell-box-style enclosed scene, 800x800, 4096 spp, 200 bounces"),
+}
 
 
 def usable_cpus():
@@ -63,19 +88,137 @@ def flops_per_sample(ctr):
     return seg * 70.0 + ctr["sphere_tests"] / n * 23.0 + ctr["node_tests"] / n * 30.0
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=WIDTH)
-    ap.add_argument("--spp", type=int, default=SPP)
-    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="3")
+    ap.add_argument("--width", type=int, default=0, help="override the config's image width (diagnostics)")
+    ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel (diagnostics)")
+    ap.add_argument("--depth", type=int, default=0, help="override the config's bounce limit (diagnostics)")
     ap.add_argument("--accel", choices=("bvh", "brute"), default="bvh")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process, N devices, through rtmi_frame_* (RCCL inside librtmi.so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-linear-scan", action="store_true", help="skip the extra linear-scan (reference algorithm) step")
-    ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline renders every n-th pixel in x and y")
-    args = ap.parse_args()
+    ap.add_argument("--no-e2e", action="store_true", help="skip the extra D2H-inclusive steps behind value_e2e")
+    ap.add_argument("--cpu-stride", type=int, default=0, help="CPU baseline renders every n-th pixel in x and y")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="CPU rehearsal of the launcher and the gather plumbing (no render, no GPU, value = 0)")
+    ap.add_argument("--rehearse-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `--gpus N` without a rendezvous in the environment.  Nothing here imports torch or touches a device.
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Starts args.gpus ranks of this script (one per GPU) as fresh child processes and relays rank 0's JSON line.
+    Worker fan-out of the reference: RayTracer::create, src/main.cc:608-712 (one std::thread per core)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"bench.py: a rank failed (torch.distributed.run exit code {proc.returncode})", file=sys.stderr)
+        return proc.returncode
+    if line is None:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 3
+    doc = json.loads(line)
+    if doc.get("n_gpus") != args.gpus:
+        print(f"bench.py: asked for {args.gpus} GPUs, the ranks report {doc.get('n_gpus')}", file=sys.stderr)
+        return 4
+    print(line, flush=True)
+    return 0
+
+
+def workload(pkg, cfg, args):
+    """(camera params, objects, materials) of a BASELINE config."""
+    width, spp, depth = args.width or cfg["width"], args.spp or cfg["spp"], args.depth or cfg["depth"]
+    if cfg["scene"] == "rtow":
+        objs, mats = pkg.make_world_spheres(SCENE_SEED)
+        kw = dict(image_width=width, samples_per_pixel=spp, max_depth=depth)
+        label = f"S-RTOW(seed {SCENE_SEED})"
+    elif cfg["scene"] == "grid":
+        objs, mats, kw = pkg.workloads.big_grid(316)
+        kw.update(image_width=width, samples_per_pixel=spp, max_depth=depth)
+        label = "S-GRID(316x316 jittered spheres over a ground sphere, seed 4)"
+    else:
+        objs, mats, kw = pkg.workloads.cornell_like()
+        kw.update(image_width=width, samples_per_pixel=spp, max_depth=depth)
+        label = "S-CORNELL(5 wall spheres R=1e3, glass + metal sphere)"
+    return kw, objs, mats, label
+
+
+def rehearse(args, world, rank):
+    """Launcher + gather plumbing on CPU tensors (gloo): every rank fills its slice with the absolute row number, rank 0
+    gathers and checks scanline order.  No render, no GPU; the line says so."""
+    import torch
+    import torch.distributed as dist
+    import rtmi_loader
+    pkg = rtmi_loader.load()
+    if world > 1:
+        dist.init_process_group(os.environ.get("RTMI_DIST_BACKEND", "gloo"))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+    if rank == args.rehearse_fail_rank:
+        raise SystemExit(7)
+    H, W = 101, 16
+    plan = pkg.RowShardPlan(H, BLOCK_ROWS, world)
+    y_first, n_blocks, rows = plan.shard(rank)
+    local = torch.full((plan.max_rows, W, 3), -1.0)
+    loc = 0
+    for k in range(n_blocks):
+        y0 = y_first + k * world * BLOCK_ROWS
+        for y in range(y0, min(H, y0 + BLOCK_ROWS)):
+            local[loc] = float(y)
+            loc += 1
+    frame = pkg.gather_frame(local, plan, rank)
+    if rank == 0:
+        assert torch.equal(frame[:, 0, 0], torch.arange(H, dtype=torch.float32)), "gathered rows out of order"
+        print(json.dumps({"metric": "launcher rehearsal (no render)", "value": 0.0, "unit": "Msamples/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "none"}, "rehearsal": True,
+                          "ranks": world, "backend": dist.get_backend() if world > 1 else "none"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and world_env is None and not args.single_process:
+        sys.exit(launch_ranks(args, argv))  # this process never touches the GPU
+
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_process:
+        if world != 1:
+            raise SystemExit("--single-process runs without torch.distributed.run")
+    elif world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse_launch:
+        return rehearse(args, world, rank)
 
     import numpy as np
     import torch
@@ -83,52 +226,62 @@ def main():
     import rtmi_loader
     pkg = rtmi_loader.load()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("RTMI_DIST_BACKEND", "nccl") != "nccl":
+    backend = os.environ.get("RTMI_DIST_BACKEND", "nccl")
+    if backend != "nccl":
         local_rank = 0  # rehearsal: every rank on the one visible GPU
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    n_gpus = args.gpus
+    if args.single_process and torch.cuda.device_count() < n_gpus:
+        raise SystemExit(f"--single-process --gpus {n_gpus} but {torch.cuda.device_count()} devices are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL ("nccl") over xGMI is the product path; RTMI_DIST_BACKEND=gloo lets two ranks share ONE GPU for a
         # rehearsal of everything but the collective itself (RCCL refuses two ranks on one device)
-        backend = os.environ.get("RTMI_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
-    cp = pkg.camera_params(image_width=args.width, samples_per_pixel=args.spp, max_depth=args.depth)
-    cam = pkg.camera_setup(cp)
-    objs, mats = pkg.make_world_spheres(SCENE_SEED)
-    W, H = cam.img_width, cam.img_height
+    cfg = CONFIGS[args.config]
+    kw, objs, mats, label = workload(pkg, cfg, args)
+    cam = pkg.camera_setup(pkg.camera_params(**kw))
+    W, H, spp, depth = cam.img_width, cam.img_height, cam.samples_per_pixel, cam.maxdepth
     accel = pkg.ACCEL_BVH if args.accel == "bvh" else pkg.ACCEL_BRUTE
-    scene = pkg.Scene(cam, objs, mats, accel=accel, device=local_rank)
+    samples = W * H * spp
 
-    plan = pkg.RowShardPlan(H, BLOCK_ROWS, world)
-    y_first, n_blocks, rows = plan.shard(rank)
-    rgb = torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev)
-    rgba = torch.zeros((plan.max_rows, W, 1), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     kernel_ms = []
+    gather_ms = []
+    if args.single_process:
+        frame_obj = pkg.Frame(cam, objs, mats, devices=tuple(range(n_gpus)), block_rows=BLOCK_ROWS, accel=accel)
+        scene = None
 
-    def step(record=False):
-        if n_blocks:
-            scene.render_row_blocks_device(y_first, BLOCK_ROWS, world, n_blocks, RENDER_SEED, rgb.data_ptr(),
-                                           rgba.data_ptr(), stream)
-        if world > 1 and dist.get_backend() != "nccl":  # rehearsal backend: stage through host memory
-            torch.cuda.synchronize(dev)
-            f, f8 = pkg.gather_frame(rgb.cpu(), plan, rank), pkg.gather_frame(rgba.cpu(), plan, rank)
-            return (f.to(dev), f8.to(dev)) if rank == 0 else (None, None)
-        frame = pkg.gather_frame(rgb, plan, rank)
-        frame8 = pkg.gather_frame(rgba, plan, rank)
-        return frame, frame8
+        def step():
+            frame_obj.render_device(RENDER_SEED)
+            t = frame_obj.timing()
+            kernel_ms.append(t["kernel_ms"])
+            gather_ms.append(t["gather_ms"])
+            return None, None
+    else:
+        scene = pkg.Scene(cam, objs, mats, accel=accel, device=local_rank)
+        plan = pkg.RowShardPlan(H, BLOCK_ROWS, world)
+        y_first, n_blocks, rows = plan.shard(rank)
+        rgb = torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev)
+        rgba = torch.zeros((plan.max_rows, W, 1), dtype=torch.int32, device=dev)
+
+        def step():
+            if n_blocks:
+                scene.render_row_blocks_device(y_first, BLOCK_ROWS, world, n_blocks, RENDER_SEED, rgb.data_ptr(),
+                                               rgba.data_ptr(), stream)
+            if world > 1 and dist.get_backend() != "nccl":  # rehearsal backend: stage through host memory
+                torch.cuda.synchronize(dev)
+                f, f8 = pkg.gather_frame(rgb.cpu(), plan, rank), pkg.gather_frame(rgba.cpu(), plan, rank)
+                return (f.to(dev), f8.to(dev)) if rank == 0 else (None, None)
+            return pkg.gather_frame(rgb, plan, rank), pkg.gather_frame(rgba, plan, rank)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -139,12 +292,14 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    kernel_ms.clear()
+    gather_ms.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame, frame8 = step()
         # per-launch duration from the HIP events the library records on the launch stream (blocks on that launch;
         # the next step cannot start earlier anyway because it reuses the same output buffers)
-        if n_blocks:
+        if scene is not None and n_blocks:
             kernel_ms.append(scene.last_kernel_ms())
     sync()
     elapsed = time.perf_counter() - t0
@@ -152,48 +307,100 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kmean = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=dev)
-    kmax = kmean.clone()
-    if world > 1:
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    # mean trace-kernel time of every rank / device
+    if args.single_process:
+        per_rank_ms = [float(np.mean([k[i] for k in kernel_ms])) for i in range(n_gpus)] if kernel_ms else [0.0] * n_gpus
+    else:
+        kmean = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=dev)
+        if world > 1:
+            allk = [torch.zeros_like(kmean) for _ in range(world)]
+            dist.all_gather(allk, kmean)
+            per_rank_ms = [float(k.item()) for k in allk]
+        else:
+            per_rank_ms = [float(kmean.item())]
+
+    # ---- the metric as SURVEY 8(d) words it: wall time including the D2H copy of the float frame (+ gather) ------------
+    e2e_elapsed, e2e_steps = None, 0
+    if not args.no_e2e and not args.single_process:
+        e2e_steps = max(1, min(args.steps, 3))
+        host = torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) if rank == 0 else None
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(e2e_steps):
+            f, _f8 = step()
+            if rank == 0:
+                host.copy_(f[:H], non_blocking=True)
+            torch.cuda.synchronize(dev)
+        sync()
+        te = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        e2e_elapsed = float(te.item())
+    elif args.single_process and not args.no_e2e:
+        e2e_steps = max(1, min(args.steps, 3))
+        t1 = time.perf_counter()
+        for _ in range(e2e_steps):
+            host_rgb, _ = frame_obj.render(RENDER_SEED)  # rtmi_frame_render: gather + D2H into host buffers
+        e2e_elapsed = time.perf_counter() - t1
 
     if rank == 0:
-        samples = W * H * args.spp
         ms_per_step = elapsed / args.steps * 1e3
         value = samples / (elapsed / args.steps) / 1e6
+        if args.single_process:
+            launcher = "one process, rtmi_frame_* (ncclCommInitAll + one grouped ncclGather inside librtmi.so)"
+            rccl_ranks = frame_obj.rccl_ranks
+        else:
+            launcher = ("torch.distributed.run, one rank per GPU, backend %s" % dist.get_backend()) if world > 1 else "one process"
+            rccl_ranks = world if (world > 1 and dist.get_backend() == "nccl") else 0
         out = {
-            "metric": "Msamples/sec (W*H*spp/s), RTOW final scene",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "metric": "Msamples/sec (W*H*spp/s), RTOW final scene" if cfg["scene"] == "rtow" else "Msamples/sec (W*H*spp/s)",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"S-RTOW(seed {SCENE_SEED}) {len(objs)} spheres, {W}x{H}, {args.spp} spp, "
-                                   f"{args.depth} bounces, accel={args.accel}",
-                       "sharding": f"interleaved {BLOCK_ROWS}-row blocks x{world}, 1 gather to rank 0",
+            "config": {"workload": f"{label} {len(objs)} spheres, {W}x{H}, {spp} spp, {depth} bounces, accel={args.accel}",
+                       "baseline_config": f"configs[{int(args.config) - 1}]: {cfg['name']}",
+                       "sharding": f"interleaved {BLOCK_ROWS}-row blocks x{n_gpus}, 1 gather to rank 0",
+                       "launcher": launcher,
                        "resident": "scene+BVH in HBM before the timed region; frame stays in HBM"},
+            "rccl_ranks": rccl_ranks,
+            "kernel_ms_per_rank": [round(k, 3) for k in per_rank_ms],
         }
+        if gather_ms:
+            out["gather_ms"] = round(float(np.mean(gather_ms)), 3)
+        if e2e_elapsed is not None:
+            out["value_e2e"] = round(samples / (e2e_elapsed / e2e_steps) / 1e6, 2)
+            out["value_e2e_note"] = (f"{e2e_steps} extra steps timed with the D2H copy of the {W}x{H} float frame into pinned "
+                                     "host memory (and the gather) inside the clock: the metric as SURVEY 8(d) words it")
+        if args.single_process:
+            frame = torch.from_numpy(host_rgb) if e2e_elapsed is not None else None
         # ---- parity spot check + algorithmic work counters from the CPU oracle (checker only) -------------
         from oracle import binding as ob
-        ocam = ob.camera_setup(ob.camera_params(image_width=args.width, samples_per_pixel=args.spp,
-                                                max_depth=args.depth))
-        frame_h = frame.cpu().numpy()
+        ocam = ob.camera_setup(ob.camera_params(**kw))
         rng = np.random.default_rng(1)
-        n_chk = 48
-        xs, ys = rng.integers(0, W, n_chk), rng.integers(0, H, n_chk)
-        worst = 0.0
-        for x, y in zip(xs, ys):
-            want, _ = ob.render_rect_counter(ocam, objs, mats, RENDER_SEED, int(x), int(y), int(x) + 1, int(y) + 1)
-            d = np.abs(frame_h[y, x] - want[0, 0])
-            d[np.isnan(frame_h[y, x]) & np.isnan(want[0, 0])] = 0.0  # the reference arithmetic can yield a NaN pixel
-            worst = max(worst, float(d.max()))
-        out["parity_check"] = {"pixels": n_chk, "max_abs_diff_vs_oracle": worst}
+        n_chk = 48 if cfg["scene"] == "rtow" else 12
+        if frame is not None:
+            frame_h = frame.cpu().numpy()
+            xs, ys = rng.integers(0, W, n_chk), rng.integers(0, H, n_chk)
+            obvh = None
+            if len(objs) > 4096:  # the oracle's own linear scan over 100k spheres takes minutes per pixel: walk the BVH
+                obvh = pkg.bvh_build(objs)
+                obvh = dict(obvh, nodes=obvh["nodes"].view(ob.BVH_NODE_DTYPE))
+            worst = 0.0
+            for x, y in zip(xs, ys):
+                want, _ = ob.render_rect_counter(ocam, objs, mats, RENDER_SEED, int(x), int(y), int(x) + 1, int(y) + 1,
+                                                 nthreads=1, bvh=obvh)
+                d = np.abs(frame_h[y, x] - want[0, 0])
+                d[np.isnan(frame_h[y, x]) & np.isnan(want[0, 0])] = 0.0  # the reference arithmetic can yield a NaN pixel
+                worst = max(worst, float(d.max()))
+            out["parity_check"] = {"pixels": n_chk, "max_abs_diff_vs_oracle": worst,
+                                   "oracle": "linear scan" if obvh is None else "instrumented BVH walk (== linear scan, tests)"}
         bvh = pkg.bvh_build(objs) if args.accel == "bvh" else None
         if bvh is not None:
             bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
         ctr_stride = 24
         ctr = {"samples": 0, "segments": 0, "sphere_tests": 0, "node_tests": 0}
-        sub_spp = min(args.spp, 64)
-        ccam = ob.camera_setup(ob.camera_params(image_width=args.width, samples_per_pixel=sub_spp,
-                                                max_depth=args.depth))
+        sub_spp = min(spp, 64)
+        ccam = ob.camera_setup(ob.camera_params(**dict(kw, samples_per_pixel=sub_spp)))
         for y in range(ctr_stride // 2, H, ctr_stride):
             for x in range(ctr_stride // 2, W, ctr_stride * 4):
                 _, _, c = ob.render_rect_counter(ccam, objs, mats, RENDER_SEED, x, y, x + 1, y + 1, counters=True,
@@ -201,20 +408,18 @@ def main():
                 for k in ctr:
                     ctr[k] += c[k]
         fps = flops_per_sample(ctr)
-        kernel_s = float(kmax.item()) / 1e3
-        samples_per_launch = samples / world
+        kernel_s = max(per_rank_ms) / 1e3
+        samples_per_launch = samples / n_gpus
         achieved = samples_per_launch * fps / kernel_s / 1e12
         traffic, traffic_note = None, None
         tpath = os.path.join(_ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                if (tj.get("width") == args.width and tj.get("spp") == args.spp and tj.get("n_gpus") == world
-                        and args.accel == "bvh"):
-                    traffic = tj.get("bytes_per_launch")
-                    traffic_note = ("2*FETCH_SIZE + WRITE_SIZE of the trace launches (profiles/hbm_traffic.json); WRITE_SIZE "
-                                    "tallies 64 B per write request: calibrated on this store pattern it reads 1.91x the "
-                                    "bytes of the 32-byte sample-record pairs (tools/ubench/write_size_calib.hip)")
+                for tj in json.load(open(tpath)).get("entries", []):
+                    if (tj.get("config") == args.config and tj.get("width") == W and tj.get("spp") == spp
+                            and tj.get("n_gpus") == n_gpus and args.accel == "bvh"):
+                        traffic = tj.get("bytes_per_launch")
+                        traffic_note = tj.get("note")
             except Exception:
                 traffic = None
         out["roofline"] = {
@@ -227,45 +432,67 @@ def main():
             # scene staged once per workgroup-resident CU + 16-byte sample records written once (the ordered resolve
             # pass reads them back) + framebuffer slice; the path is VALU-bound, HBM is reported as a sanity check
             "hbm_algorithmic_bytes_per_launch": int(len(objs) * (16 + 16 + 32) + (0 if bvh is None else len(bvh["nodes"]) * 64)
-                                                    + samples_per_launch * 16 + W * (H // world) * 16),
+                                                    + samples_per_launch * 16 + W * (H // n_gpus) * 16),
             "note": "fp32 VALU-bound path (SURVEY 8d): peak = non-FMA issue rate 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
         }
-        # ---- the reference's own algorithm on the GPU: linear closest-hit scan, same frame, one untimed-in-`value` step --
-        if world == 1 and args.accel == "bvh" and not args.no_linear_scan:
-            bvh_frame = frame.clone()  # `frame` is a view of `rgb` at world == 1
+        # ---- the reference's own algorithm on the GPU: linear closest-hit scan on the same frame (or a uniform subset of
+        # its row blocks where the whole frame would take minutes), outside the timed region ----------------------------
+        lin_rate = None
+        if world == 1 and not args.single_process and args.accel == "bvh" and not args.no_linear_scan:
+            y_lin, s_lin, n_lin = cfg["lin"] or (0, 1, (H + BLOCK_ROWS - 1) // BLOCK_ROWS)
+            if args.width or H <= y_lin + (n_lin - 1) * s_lin * BLOCK_ROWS:
+                y_lin, s_lin, n_lin = 0, 1, (H + BLOCK_ROWS - 1) // BLOCK_ROWS
+            lin_rows = sum(min(BLOCK_ROWS, H - (y_lin + k * s_lin * BLOCK_ROWS)) for k in range(n_lin))
+            want = torch.zeros((lin_rows, W, 3), dtype=torch.float32, device=dev)
+            scene.render_row_blocks_device(y_lin, BLOCK_ROWS, s_lin, n_lin, RENDER_SEED, want.data_ptr(), 0, stream)
+            torch.cuda.synchronize(dev)
+            got = torch.zeros_like(want)
             lin = pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BRUTE, device=local_rank)
-            lin.render_row_blocks_device(0, H, 1, 1, RENDER_SEED, rgb.data_ptr(), 0, stream)
-            torch.cuda.synchronize(dev)
-            lin.render_row_blocks_device(0, H, 1, 1, RENDER_SEED, rgb.data_ptr(), 0, stream)
-            torch.cuda.synchronize(dev)
-            lin_ms = lin.last_kernel_ms()
+            lin_ms = None
+            for _ in range(2 if cfg["lin"] is None else 1):
+                lin.render_row_blocks_device(y_lin, BLOCK_ROWS, s_lin, n_lin, RENDER_SEED, got.data_ptr(), 0, stream)
+                torch.cuda.synchronize(dev)
+                lin_ms = lin.last_kernel_ms()
             lin.close()
-            same = bool(torch.equal(torch.nan_to_num(rgb[:H]).view(torch.int32), torch.nan_to_num(bvh_frame).view(torch.int32)))
+            same = bool(torch.equal(torch.nan_to_num(got).view(torch.int32), torch.nan_to_num(want).view(torch.int32)))
+            lin_samples = lin_rows * W * spp
             lin_fps = ctr["segments"] / ctr["samples"] * (len(objs) * 23.0 + 70.0)
+            lin_rate = lin_samples / lin_ms / 1e3
             out["linear_scan_kernel"] = {
-                "value": round(samples / lin_ms / 1e3, 2), "unit": "Msamples/s", "kernel_ms": round(lin_ms, 3),
+                "value": round(lin_rate, 3), "unit": "Msamples/s", "kernel_ms": round(lin_ms, 3),
+                "rows": f"{lin_rows} of {H} (blocks of {BLOCK_ROWS} rows, every {s_lin}th from row {y_lin})",
                 "flops_per_sample": round(lin_fps, 1),
-                "roofline_frac": round(samples * lin_fps / (lin_ms / 1e3) / 1e12 / VALU_PEAK_TFLOPS, 4),
+                "roofline_frac": round(lin_samples * lin_fps / (lin_ms / 1e3) / 1e12 / VALU_PEAK_TFLOPS, 4),
                 "frame_bit_identical_to_bvh": same,
-                "note": "rtmi_trace_kernel<brute>: the reference's O(N) scan (object.defs.cc:68-81), spheres in LDS; "
-                        "the BVH walk returns the same frame with ~17x less algorithmic work",
+                "note": "rtmi_trace_kernel<brute>: the reference's O(N) scan (object.defs.cc:68-81); the BVH walk returns "
+                        "the same frame with far less algorithmic work",
             }
         # ---- CPU baseline: the oracle, reference-shaped job system, on this host's cores -----------------------
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.single_process and not args.no_cpu_baseline:
             hw = usable_cpus()
             threads = hw - 2 if hw > 6 else hw  # src/main.cc:608-611
-            secs, n = ob.bench_mt(ocam, objs, mats, SCENE_SEED, args.cpu_stride, threads)
-            secs1, n1 = ob.bench_mt(ocam, objs, mats, SCENE_SEED, args.cpu_stride * 6, 1)
+            stride = args.cpu_stride or cfg["cpu_stride"]
+            secs, n = ob.bench_mt(ocam, objs, mats, SCENE_SEED, stride, threads)
             out["cpu_baseline"] = {
-                "value": round(n / secs / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-                "sample": f"every {args.cpu_stride}th pixel in x and y of the same frame at full spp "
-                          f"({n} samples, {secs:.1f} s); mt19937 per worker, shuffled 8x8 tiles (src/main.cc:608-633)",
-                "single_thread_value": round(n1 / secs1 / 1e6, 4), "host_cpus": hw,
+                "value": round(n / secs / 1e6, 5), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                "sample": f"every {stride}th pixel in x and y of the same frame at full spp "
+                          f"({n} samples, {secs:.1f} s); the reference's linear scan, mt19937 per worker, shuffled 8x8 "
+                          f"tiles (src/main.cc:608-633)",
+                "host_cpus": hw,
             }
+            if cfg["scene"] == "rtow":
+                secs1, n1 = ob.bench_mt(ocam, objs, mats, SCENE_SEED, stride * 6, 1)
+                out["cpu_baseline"]["single_thread_value"] = round(n1 / secs1 / 1e6, 5)
             out["gpu_over_cpu"] = round(value / (n / secs / 1e6), 1)
+            out["gpu_over_cpu_note"] = "GPU: BVH walk (same frame as the scan, bit for bit); CPU: the reference's linear scan"
+            if lin_rate is not None:
+                out["gpu_over_cpu_like_for_like"] = round(lin_rate / (n / secs / 1e6), 1)
         print(json.dumps(out), flush=True)
 
-    scene.close()
+    if scene is not None:
+        scene.close()
+    if args.single_process:
+        frame_obj.close()
     if world > 1:
         dist.destroy_process_group()
 

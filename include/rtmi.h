@@ -33,7 +33,9 @@ typedef enum rtmi_status {
     RTMI_ERR_BAD_ARG = -1,   /* null pointer, out-of-range rows, bad material handle, unknown kind */
     RTMI_ERR_HIP = -2,       /* a HIP runtime call failed (no device, launch failure, ...) */
     RTMI_ERR_OOM = -3,       /* host or device allocation failed */
-    RTMI_ERR_UNSUPPORTED = -4 /* scene does not fit the selected kernel (e.g. LDS budget) */
+    RTMI_ERR_UNSUPPORTED = -4, /* scene does not fit the selected kernel (e.g. LDS budget) */
+    RTMI_ERR_RCCL = -5,       /* an RCCL call of the multi-device frame failed (or librccl could not be loaded) */
+    RTMI_ERR_INTERNAL = -6    /* an unexpected C++ exception was caught at the boundary (never propagated) */
 } rtmi_status;
 
 /* CameraParameters, reference src/camera.parameters.hpp:6-17 (same fields, order and types). */
@@ -98,13 +100,32 @@ typedef enum rtmi_accel {
     RTMI_ACCEL_BVH = 2    /* exact-equivalent BVH walk (same closest hit, same tie rule), nodes in LDS */
 } rtmi_accel;
 
+/* Scheduling knobs.  None of them changes a bit of the image (the draw streams are keyed by absolute pixel and
+ * sample); they exist for tuning and for the tests that prove exactly that.  0 = library default everywhere.
+ * The library reads no environment variables. */
+typedef struct rtmi_tuning {
+    uint32_t struct_size;       /* = sizeof(rtmi_tuning) */
+    uint32_t block_lanes;       /* lanes per workgroup, multiple of 64 (default 768: 2 x 768 per CU = 6 waves per SIMD) */
+    uint32_t blocks_per_cu;     /* cap on resident workgroups per CU (default: the occupancy query) */
+    uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 56) */
+    uint32_t drain_wait_thresh; /* the same for the launch that finishes deferred paths (default 56) */
+    int32_t chunk_samples;      /* samples per work item: 0 = auto, -1 = whole pixels (no sample records), n > 0 = n */
+    int32_t defer_mode;         /* deferred-path queue: 0 = auto (on for long launches), 1 = on, -1 = off */
+    uint32_t defer_cap;         /* capacity of that queue in records (default: 1/16 of the samples of the launch) */
+    uint32_t sample_buf_mb;     /* cap on the sample-record buffer in MiB (default 24576); larger calls run in row bands */
+    uint32_t force_hbm_scene;   /* nonzero: leave the scene in HBM even when it fits LDS (the config-4 path) */
+    uint32_t top_down;          /* nonzero: hand out tiles top row first instead of bottom row first */
+    uint32_t reserved[5];
+} rtmi_tuning;
+
 typedef struct rtmi_scene_options {
     uint32_t struct_size;  /* = sizeof(rtmi_scene_options) */
     uint32_t accel;        /* rtmi_accel */
     uint32_t leaf_size;    /* BVH: max spheres per leaf (0 = default) */
-    int32_t device;        /* HIP device ordinal, -1 = current device */
+    int32_t device;        /* HIP device ordinal, -1 = the caller's current device (also when options == NULL) */
     uint32_t collect_stats;/* nonzero: kernels also count segments / node tests / sphere tests */
     uint32_t reserved[3];
+    const rtmi_tuning* tuning; /* NULL = defaults */
 } rtmi_scene_options;
 
 typedef struct rtmi_stats {
@@ -137,7 +158,9 @@ int rtmi_make_world_spheres(const rtmi_world_def* def, const rtmi_object* fixed_
 /* ---- scene life cycle (replaces the ownership of shared_ptr<RayTracingCore>, main.cc:433,604,669-672) ---- */
 
 /* Uploads camera + world + materials (the reference's rts_world / rts_materials, core.hpp:33-34) and builds
- * the acceleration structure.  `options` may be NULL. */
+ * the acceleration structure.  `options` may be NULL (= BVH/scan chosen by size, the caller's current device).
+ * Objects with a non-finite centre or radius are rejected (RTMI_ERR_BAD_ARG): the reference would trace NaNs, a
+ * bounding volume cannot hold them.  Every entry point leaves the caller's current HIP device as it found it. */
 int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
                       const rtmi_material* materials, uint32_t n_materials, const rtmi_scene_options* options,
                       rtmi_scene** out);
@@ -184,6 +207,37 @@ int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf
  * not included), from HIP events recorded on the launch stream; blocks until that launch has finished.  Used by
  * bench.py for the roofline line. */
 int rtmi_scene_last_kernel_ms(rtmi_scene* scene, float* ms_out);
+
+/* ---- one frame on several GPUs of one node (replaces the worker fan-out of RayTracer::create, main.cc:586-731,
+ *      and the per-frame drain of RayTracer::update, main.cc:733-774) -------------------------------------------
+ * One process, n devices.  The image plane is sharded by interleaved row blocks (block b -> device b mod n, so the
+ * cheap sky rows and the expensive ground rows are spread evenly); every device holds a replica of the scene and
+ * renders its blocks into a dense slice; ONE RCCL gather (ncclGather inside ncclGroupStart/End, over xGMI) brings
+ * the slices to devices[0], where a small kernel restores scanline order.  The frame is bit-identical for any n
+ * (the draw streams are keyed by absolute pixel and sample).  With n == 1 no communicator is created. */
+typedef struct rtmi_frame rtmi_frame; /* opaque: scene replicas, streams, slices, RCCL communicators */
+
+typedef struct rtmi_frame_timing {
+    float total_ms;       /* first launch -> frame in scanline order on devices[0] (host wall clock, blocking call) */
+    float gather_ms;      /* RCCL gather + de-interleave on devices[0] (HIP events on its stream) */
+    float kernel_ms[16];  /* trace-kernel time of each device (HIP events), first n entries valid */
+} rtmi_frame_timing;
+
+/* `options->device` is ignored (the list decides); `devices` = HIP ordinals, distinct, 1 <= n <= 16;
+ * `block_rows` = rows per shard block (0 = 8). */
+int rtmi_frame_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
+                      const rtmi_material* materials, uint32_t n_materials, const rtmi_scene_options* options,
+                      const int32_t* devices, uint32_t n_devices, uint32_t block_rows, rtmi_frame** out);
+void rtmi_frame_destroy(rtmi_frame* frame);
+/* Renders the whole frame.  Host outputs (either may be NULL): H*W*3 floats / H*W uint32, as rtmi_render_rows.
+ * Blocking; externally synchronised (one call at a time per frame object). */
+int rtmi_frame_render(rtmi_frame* frame, uint64_t seed, float* rgb_linear_out, uint32_t* rgba8_out);
+/* Same, but the frame stays on devices[0]: returns pointers (owned by the frame object, valid until the next
+ * render or destroy) to H*W*3 floats and H*W uint32 in scanline order.  Blocking. */
+int rtmi_frame_render_device(rtmi_frame* frame, uint64_t seed, void** d_rgb_linear, void** d_rgba8);
+int rtmi_frame_get_timing(const rtmi_frame* frame, rtmi_frame_timing* out);
+/* number of RCCL ranks behind the frame (0 when n_devices == 1: no communicator) */
+int rtmi_frame_rccl_ranks(const rtmi_frame* frame, uint32_t* n_out);
 
 #ifdef __cplusplus
 }

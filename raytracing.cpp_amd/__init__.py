@@ -18,7 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "librtmi.so")
-CSRC = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_host.cpp", "rtmi_device.hip")]
+CSRC = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_host.cpp", "rtmi_device.hip", "rtmi_frame.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "rtmi_internal.h"), os.path.join(_ROOT, "include", "rtmi.h")]
 
 HIPCC_FLAGS = [
@@ -31,7 +31,7 @@ HIPCC_FLAGS = [
 ]
 
 RTMI_OK = 0
-RTMI_ERR_BAD_ARG, RTMI_ERR_HIP, RTMI_ERR_OOM, RTMI_ERR_UNSUPPORTED = -1, -2, -3, -4
+RTMI_ERR_BAD_ARG, RTMI_ERR_HIP, RTMI_ERR_OOM, RTMI_ERR_UNSUPPORTED, RTMI_ERR_RCCL, RTMI_ERR_INTERNAL = -1, -2, -3, -4, -5, -6
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
 
 
@@ -42,7 +42,7 @@ def build_library(force=False, verbose=False):
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(_ROOT, "include"), "-o", LIB_PATH] + CSRC
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(_ROOT, "include"), "-o", LIB_PATH] + CSRC + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -70,9 +70,42 @@ class WorldDef(C.Structure):  # rtmi_world_def == reference src/ray.tracer.core.
                 ("diffuse_material_treshold", C.c_float), ("metal_material_treshold", C.c_float)]
 
 
+class Tuning(C.Structure):  # rtmi_tuning: scheduling knobs, 0 = default; none of them changes the image
+    _fields_ = [("struct_size", C.c_uint32), ("block_lanes", C.c_uint32), ("blocks_per_cu", C.c_uint32),
+                ("wait_thresh", C.c_uint32), ("drain_wait_thresh", C.c_uint32), ("chunk_samples", C.c_int32),
+                ("defer_mode", C.c_int32), ("defer_cap", C.c_uint32), ("sample_buf_mb", C.c_uint32),
+                ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+
+
 class SceneOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("accel", C.c_uint32), ("leaf_size", C.c_uint32), ("device", C.c_int32),
-                ("collect_stats", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("collect_stats", C.c_uint32), ("reserved", C.c_uint32 * 3), ("tuning", C.POINTER(Tuning))]
+
+
+class FrameTiming(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("gather_ms", C.c_float), ("kernel_ms", C.c_float * 16)]
+
+
+def make_tuning(**kw):
+    """rtmi_tuning from keyword arguments (field names of include/rtmi.h); unknown names are an error."""
+    t = Tuning()
+    t.struct_size = C.sizeof(Tuning)
+    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved"}
+    for k, v in kw.items():
+        if k not in names:
+            raise KeyError(f"unknown tuning knob {k!r}")
+        setattr(t, k, int(v))
+    return t
+
+
+def _options(accel, leaf_size, device, collect_stats, tuning):
+    opt = SceneOptions()
+    opt.struct_size = C.sizeof(SceneOptions)
+    opt.accel, opt.leaf_size, opt.device, opt.collect_stats = accel, leaf_size, device, int(collect_stats)
+    tun = make_tuning(**tuning) if tuning else None
+    if tun is not None:
+        opt.tuning = C.pointer(tun)
+    return opt, tun  # keep `tun` alive while `opt` is in use
 
 
 class Stats(C.Structure):
@@ -80,8 +113,9 @@ class Stats(C.Structure):
                 ("node_tests", C.c_uint64)]
 
 
-OBJECT_DTYPE = np.dtype([("kind", "<u4"), ("center", "<f4", 3), ("radius", "<f4"), ("material", "<u4")])
-MATERIAL_DTYPE = np.dtype([("kind", "<u4"), ("p", "<f4", 4)])
+from . import workloads  # noqa: E402  (scene + camera generators of the BASELINE configs)
+
+OBJECT_DTYPE, MATERIAL_DTYPE = workloads.OBJECT_DTYPE, workloads.MATERIAL_DTYPE
 BVH_NODE_DTYPE = np.dtype([("ctr", "<f4", (2, 3)), ("half", "<f4", (2, 3)), ("child", "<u4", 2),
                            ("reserved", "<f4", 2)])
 assert OBJECT_DTYPE.itemsize == 24 and MATERIAL_DTYPE.itemsize == 20 and BVH_NODE_DTYPE.itemsize == 64
@@ -90,7 +124,8 @@ assert OBJECT_DTYPE.itemsize == 24 and MATERIAL_DTYPE.itemsize == 20 and BVH_NOD
 EXPORTS = ("rtmi_camera_setup", "rtmi_make_world_spheres", "rtmi_scene_create", "rtmi_scene_destroy",
            "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_last_error", "rtmi_version",
            "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
-           "rtmi_bvh_build")
+           "rtmi_bvh_build", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
+           "rtmi_frame_render_device", "rtmi_frame_get_timing", "rtmi_frame_rccl_ranks")
 
 _lib = None
 
@@ -130,8 +165,16 @@ def lib():
     L.rtmi_scene_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     u32p, f32p = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
     L.rtmi_bvh_build.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u32p, vp, u32p, u32p, vp, u32p, f32p, f32p]
+    L.rtmi_frame_create.argtypes = [C.POINTER(Camera), vp, C.c_uint32, vp, C.c_uint32, C.POINTER(SceneOptions),
+                                    C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.rtmi_frame_destroy.argtypes = [vp]
+    L.rtmi_frame_destroy.restype = None
+    L.rtmi_frame_render.argtypes = [vp, C.c_uint64, vp, vp]
+    L.rtmi_frame_render_device.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
+    L.rtmi_frame_get_timing.argtypes = [vp, C.POINTER(FrameTiming)]
+    L.rtmi_frame_rccl_ranks.argtypes = [vp, C.POINTER(C.c_uint32)]
     for name in EXPORTS:
-        if name not in ("rtmi_last_error", "rtmi_version", "rtmi_scene_destroy"):
+        if name not in ("rtmi_last_error", "rtmi_version", "rtmi_scene_destroy", "rtmi_frame_destroy"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -208,12 +251,10 @@ def make_world_spheres(seed=12345, wd=None, fixed=None):
 class Scene:
     """Owns an rtmi_scene handle (device copies of camera, world, materials, BVH)."""
 
-    def __init__(self, cam, objs, mats, accel=ACCEL_AUTO, leaf_size=0, device=-1, collect_stats=False):
+    def __init__(self, cam, objs, mats, accel=ACCEL_AUTO, leaf_size=0, device=-1, collect_stats=False, tuning=None):
         objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
         mats = np.ascontiguousarray(mats, dtype=MATERIAL_DTYPE)
-        opt = SceneOptions()
-        opt.struct_size = C.sizeof(SceneOptions)
-        opt.accel, opt.leaf_size, opt.device, opt.collect_stats = accel, leaf_size, device, int(collect_stats)
+        opt, _tun = _options(accel, leaf_size, device, collect_stats, tuning)
         self._h = C.c_void_p()
         self.cam = cam
         self.width, self.height = cam.img_width, cam.img_height
@@ -275,6 +316,58 @@ class Scene:
         pc = np.zeros((nc.value, 8), np.float32)
         _check(lib().rtmi_scene_get_bvh(self._h, _ptr(nodes), None, _ptr(slots), None, _ptr(pc), None, None, None))
         return dict(nodes=nodes, slots=slots, pad_classes=pc, pad_eps=eps.value, pad_floor=floor.value)
+
+
+class Frame:
+    """Owns an rtmi_frame handle: one frame on several GPUs of one node, one process (rtmi_frame_*): scene replicas,
+    interleaved row-block shards, one RCCL gather to devices[0]."""
+
+    def __init__(self, cam, objs, mats, devices=(0,), block_rows=8, accel=ACCEL_AUTO, leaf_size=0, tuning=None):
+        objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
+        mats = np.ascontiguousarray(mats, dtype=MATERIAL_DTYPE)
+        opt, _tun = _options(accel, leaf_size, -1, False, tuning)
+        devs = (C.c_int32 * len(devices))(*devices)
+        self._h = C.c_void_p()
+        self.width, self.height, self.n_devices = cam.img_width, cam.img_height, len(devices)
+        _check(lib().rtmi_frame_create(C.byref(cam), _ptr(objs), len(objs), _ptr(mats), len(mats), C.byref(opt), devs,
+                                       len(devices), block_rows, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rtmi_frame_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def render(self, seed):
+        """rtmi_frame_render: the whole frame into host buffers."""
+        rgb = np.zeros((self.height, self.width, 3), np.float32)
+        rgba = np.zeros((self.height, self.width), np.uint32)
+        _check(lib().rtmi_frame_render(self._h, seed, _ptr(rgb), _ptr(rgba)))
+        return rgb, rgba
+
+    def render_device(self, seed):
+        """rtmi_frame_render_device: the frame stays on devices[0]; returns the two device pointers (ints)."""
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(lib().rtmi_frame_render_device(self._h, seed, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def timing(self):
+        t = FrameTiming()
+        _check(lib().rtmi_frame_get_timing(self._h, C.byref(t)))
+        return dict(total_ms=t.total_ms, gather_ms=t.gather_ms, kernel_ms=list(t.kernel_ms)[:self.n_devices])
+
+    @property
+    def rccl_ranks(self):
+        v = C.c_uint32(0)
+        _check(lib().rtmi_frame_rccl_ranks(self._h, C.byref(v)))
+        return v.value
 
 
 def bvh_build(objs, leaf_size=0):

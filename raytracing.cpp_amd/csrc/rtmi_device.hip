@@ -985,6 +985,37 @@ __global__ void __launch_bounds__(256) rtmi_resolve_kernel(const float4* __restr
         }                                                                                                    \
     } while (0)
 
+// every entry point leaves the caller's current device as it found it
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            prev = -1;
+            (void)hipGetLastError();
+        }
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// nothing is thrown across the C-ABI: std::vector growth in the BVH builder, std::string in set_error ...
+template <class F>
+static int guarded(const char* where, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try { set_error(std::string(where) + ": out of host memory"); } catch (...) {}
+        return RTMI_ERR_OOM;
+    } catch (const std::exception& e) {
+        try { set_error(std::string(where) + ": " + e.what()); } catch (...) {}
+        return RTMI_ERR_INTERNAL;
+    } catch (...) {
+        try { set_error(std::string(where) + ": unknown exception"); } catch (...) {}
+        return RTMI_ERR_INTERNAL;
+    }
+}
+
 struct rtmi_scene {
     rtmi_camera cam{};
     int device = 0;
@@ -1012,6 +1043,8 @@ struct rtmi_scene {
     uint4* d_defer = nullptr;    // deferred-path queue
     uint32_t defer_cap = 0;
     int defer_mode = 2;        // 0 off, 1 on, 2 auto: on for launches long enough to pay for the second launch
+    uint32_t defer_cap_req = 0; // rtmi_tuning::defer_cap (0: sized from the launch)
+    bool top_down = false;
     // launch geometry
     uint32_t block = 768, grid = 0, lds_bytes = 0, stack_depth = 0; // 2 x 768 lanes per CU = 6 waves per SIMD (<= 80 VGPRs)
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
@@ -1122,7 +1155,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.n_local_rows = n_local_rows;
     P.tiles_x = (W + 7u) / 8u;
     P.tiles_y = (n_local_rows + 7u) / 8u;
-    P.top_down = std::getenv("RTMI_TOPDOWN") ? 1u : 0u;
+    P.top_down = s->top_down ? 1u : 0u;
     // sample-chunk split: the cost of a pixel is heavy-tailed (paths trapped in the ground sphere run 50 bounces), so a
     // launch whose work items are whole pixels ends in a long tail (29 % of a 1080p x 512 spp frame, measured); items
     // of `chunk` samples cut it by spp / chunk at the price of 16 B per sample written once and read once.
@@ -1169,10 +1202,11 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     // A/B on MI355X, 1080p x 512 spp split over N ranks: the drain launch pays off for the whole frame (+2 %), half of
     // it (+1.8 %) and a quarter (+0.6 %); for an eighth (133 M samples, 340 per lane) its own ramp and tail cost 3 %
     const bool defer_pays = (uint64_t)n_local_rows * W * spp >= 512ull * s->grid * s->block;
+    // (a queue record packs the pixel as x | y << 16: launches wider or taller than 65535 keep their paths)
     if (P.sample_buf && (s->defer_mode == 1 || (s->defer_mode == 2 && defer_pays)) && !s->big &&
-        s->accel == RTMI_ACCEL_BVH && s->cam.maxdepth >= 16) {
+        s->accel == RTMI_ACCEL_BVH && s->cam.maxdepth >= 16 && W <= 0xffffu && n_local_rows <= 0xffffu) {
         uint64_t want = std::min<uint64_t>((uint64_t)n_local_rows * W * spp / 16u + 65536u, 0x7fffffffull / 5u);
-        if (const char* e = std::getenv("RTMI_DEFER_CAP")) want = (uint64_t)std::max(64, std::atoi(e)); // tests: force overflow
+        if (s->defer_cap_req) want = std::max<uint64_t>(64u, s->defer_cap_req); // tests: force overflow
         if (want > s->defer_cap) {
             hipFree(s->d_defer);
             s->d_defer = nullptr;
@@ -1276,14 +1310,10 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
 
 } // namespace
 
-extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
-                                 const rtmi_material* materials, uint32_t n_materials,
-                                 const rtmi_scene_options* options, rtmi_scene** out) {
-    if (!camera || !out || (n_objects && !objects) || (n_materials && !materials)) {
-        set_error("rtmi_scene_create: null argument");
-        return RTMI_ERR_BAD_ARG;
-    }
-    *out = nullptr;
+// `s` is handed back to the wrapper below, which frees it on any failure (status or exception)
+static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
+                             const rtmi_material* materials, uint32_t n_materials, const rtmi_scene_options* options,
+                             rtmi_scene*& s) {
     if (camera->samples_per_pixel == 0) {
         set_error("rtmi_scene_create: samples_per_pixel must be at least 1");
         return RTMI_ERR_BAD_ARG;
@@ -1305,17 +1335,25 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
         }
     }
     rtmi_scene_options opt{};
+    opt.device = -1; // the caller's current device, also for options == NULL or a short struct
     if (options) std::memcpy(&opt, options, std::min<size_t>(sizeof(opt), options->struct_size));
+    rtmi_tuning tune{};
+    if (opt.tuning) std::memcpy(&tune, opt.tuning, std::min<size_t>(sizeof(tune), opt.tuning->struct_size));
+    for (uint32_t i = 0; i < n_objects; ++i) {
+        const rtmi_object& o = objects[i];
+        if (!std::isfinite(o.center[0]) || !std::isfinite(o.center[1]) || !std::isfinite(o.center[2]) ||
+            !std::isfinite(o.radius)) {
+            set_error("rtmi_scene_create: object with a non-finite centre or radius");
+            return RTMI_ERR_BAD_ARG;
+        }
+    }
 
-    rtmi_scene* s = new (std::nothrow) rtmi_scene();
+    s = new (std::nothrow) rtmi_scene();
     if (!s) {
         set_error("rtmi_scene_create: out of host memory");
         return RTMI_ERR_OOM;
     }
-    auto fail = [&](int rc) {
-        free_scene(s);
-        return rc;
-    };
+    auto fail = [&](int rc) { return rc; };
 #define HIP_TRY_S(expr)                                                                  \
     do {                                                                                 \
         hipError_t e_ = (expr);                                                          \
@@ -1371,7 +1409,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
         h_mats[i] = make_uint4(fbits(m.p[0]), fbits(m.p[1]), fbits(m.p[2]), fbits(m.p[3]));
     }
 
-    if (const char* e = std::getenv("RTMI_BLOCK")) s->block = (uint32_t)std::min(1024, std::max(64, (std::atoi(e) / 64) * 64));
+    if (tune.block_lanes) s->block = std::min(1024u, std::max(64u, (tune.block_lanes / 64u) * 64u));
     // LDS carve-up.  Small scenes live in LDS entirely (two workgroups per CU must fit: 80 KiB each); larger ones
     // stay in HBM and only the traversal stack is in LDS.
     auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
@@ -1380,7 +1418,7 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     const uint64_t small_total = scene_bytes + (uint64_t)s->stack_depth * s->block * 2u + 64u;
     s->big = small_total + kAttLds * s->block * 4u > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u ||
              n_objects > 0x2000u || n_materials > 0x10000u;
-    if (const char* e = std::getenv("RTMI_FORCE_BIG")) s->big = s->big || std::atoi(e) != 0;
+    if (tune.force_hbm_scene) s->big = true;
     uint32_t off = 0;
     if (!s->big) {
         s->lds_nodes = off;
@@ -1468,12 +1506,14 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     }
     hipDeviceProp_t prop;
     HIP_TRY_S(hipGetDeviceProperties(&prop, dev));
-    if (const char* e = std::getenv("RTMI_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));
-    if (const char* e = std::getenv("RTMI_WAIT_THRESH")) s->wait_thresh = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("RTMI_CHUNK")) s->chunk = (uint32_t)std::max(0, std::atoi(e)); // 0: split off
-    if (const char* e = std::getenv("RTMI_DEFER")) s->defer_mode = std::atoi(e) != 0 ? 1 : 0;
-    if (const char* e = std::getenv("RTMI_DRAIN_WAIT")) s->drain_wait_thresh = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("RTMI_SAMPLE_BUF_MB")) s->sample_buf_cap_bytes = (size_t)std::max(0, std::atoi(e)) << 20;
+    if (tune.blocks_per_cu) per_cu = std::max(1, std::min(per_cu, (int)tune.blocks_per_cu));
+    if (tune.wait_thresh) s->wait_thresh = std::min(64u, tune.wait_thresh);
+    if (tune.chunk_samples) s->chunk = tune.chunk_samples < 0 ? 0u : (uint32_t)tune.chunk_samples; // 0: split off
+    if (tune.defer_mode) s->defer_mode = tune.defer_mode > 0 ? 1 : 0;
+    s->defer_cap_req = tune.defer_cap;
+    if (tune.drain_wait_thresh) s->drain_wait_thresh = std::min(64u, tune.drain_wait_thresh);
+    if (tune.sample_buf_mb) s->sample_buf_cap_bytes = (size_t)tune.sample_buf_mb << 20;
+    s->top_down = tune.top_down != 0;
     s->grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
 
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_counter), 16));
@@ -1486,27 +1526,53 @@ extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* o
     HIP_TRY_S(hipEventCreate(&s->ev1));
     HIP_TRY_S(hipEventCreate(&s->ev2));
 #undef HIP_TRY_S
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
+                                 const rtmi_material* materials, uint32_t n_materials,
+                                 const rtmi_scene_options* options, rtmi_scene** out) {
+    if (!camera || !out || (n_objects && !objects) || (n_materials && !materials)) {
+        try { set_error("rtmi_scene_create: null argument"); } catch (...) {}
+        return RTMI_ERR_BAD_ARG;
+    }
+    *out = nullptr;
+    DeviceGuard guard;
+    rtmi_scene* s = nullptr;
+    const int rc = guarded("rtmi_scene_create", [&] {
+        return scene_create_impl(camera, objects, n_objects, materials, n_materials, options, s);
+    });
+    if (rc != RTMI_OK) {
+        free_scene(s);
+        return rc;
+    }
     *out = s;
     return RTMI_OK;
 }
 
-extern "C" void rtmi_scene_destroy(rtmi_scene* scene) { free_scene(scene); }
+extern "C" void rtmi_scene_destroy(rtmi_scene* scene) {
+    DeviceGuard guard;
+    free_scene(scene);
+}
 
 extern "C" int rtmi_render_row_blocks_device(rtmi_scene* s, uint32_t y_first, uint32_t block_rows,
                                              uint32_t block_stride, uint32_t n_blocks, uint64_t seed,
                                              void* d_rgb_linear_out, void* d_rgba8_out, void* hip_stream) {
-    if (!s) {
-        set_error("rtmi_render_row_blocks_device: null scene");
-        return RTMI_ERR_BAD_ARG;
-    }
-    std::lock_guard<std::mutex> lock(s->mu);
-    HIP_TRY(hipSetDevice(s->device));
-    return launch(s, y_first, block_rows, block_stride, n_blocks, seed, static_cast<float*>(d_rgb_linear_out),
-                  static_cast<uint32_t*>(d_rgba8_out), static_cast<hipStream_t>(hip_stream));
+    DeviceGuard guard;
+    return guarded("rtmi_render_row_blocks_device", [&]() -> int {
+        if (!s) {
+            set_error("rtmi_render_row_blocks_device: null scene");
+            return RTMI_ERR_BAD_ARG;
+        }
+        std::lock_guard<std::mutex> lock(s->mu);
+        HIP_TRY(hipSetDevice(s->device));
+        return launch(s, y_first, block_rows, block_stride, n_blocks, seed, static_cast<float*>(d_rgb_linear_out),
+                      static_cast<uint32_t*>(d_rgba8_out), static_cast<hipStream_t>(hip_stream));
+    });
 }
 
-extern "C" int rtmi_render_rows(rtmi_scene* s, uint32_t y0, uint32_t y1, uint64_t seed, float* rgb_linear_out,
-                                uint32_t* rgba8_out) {
+static int render_rows_impl(rtmi_scene* s, uint32_t y0, uint32_t y1, uint64_t seed, float* rgb_linear_out,
+                            uint32_t* rgba8_out) {
     if (!s) {
         set_error("rtmi_render_rows: null scene");
         return RTMI_ERR_BAD_ARG;
@@ -1542,7 +1608,14 @@ extern "C" int rtmi_render_rows(rtmi_scene* s, uint32_t y0, uint32_t y1, uint64_
     return RTMI_OK;
 }
 
+extern "C" int rtmi_render_rows(rtmi_scene* s, uint32_t y0, uint32_t y1, uint64_t seed, float* rgb_linear_out,
+                                uint32_t* rgba8_out) {
+    DeviceGuard guard;
+    return guarded("rtmi_render_rows", [&] { return render_rows_impl(s, y0, y1, seed, rgb_linear_out, rgba8_out); });
+}
+
 extern "C" int rtmi_scene_get_stats(rtmi_scene* s, rtmi_stats* out, int reset) {
+    DeviceGuard guard;
     if (!s || !out) {
         set_error("rtmi_scene_get_stats: null argument");
         return RTMI_ERR_BAD_ARG;
@@ -1596,6 +1669,7 @@ extern "C" int rtmi_scene_last_kernel_ms(rtmi_scene* s, float* ms_out) {
         set_error("rtmi_scene_last_kernel_ms: null argument");
         return RTMI_ERR_BAD_ARG;
     }
+    DeviceGuard guard;
     std::lock_guard<std::mutex> lock(s->mu);
     if (!s->ev_valid) {
         set_error("rtmi_scene_last_kernel_ms: no launch yet");

@@ -1,0 +1,399 @@
+// rtmi_frame.hip -- one frame on several GPUs of one node, behind the C-ABI (include/rtmi.h, rtmi_frame_*).
+//
+// Replaces the worker fan-out of the reference's RayTracer::create (src/main.cc:586-731: one std::thread per core,
+// a shuffled queue of 8x8 tiles) and the per-frame drain of RayTracer::update (src/main.cc:733-774: ZeroMQ inproc
+// mailboxes, one message per pixel) by: one scene replica per device, the image plane sharded by interleaved row
+// blocks (block b -> device b mod n), ONE RCCL gather of the dense per-device slices over xGMI to devices[0], and a
+// small kernel that restores scanline order.  No exchange happens during rendering: pixels are independent and the
+// draw streams are keyed by absolute (pixel, sample), so the frame is bit-identical for any n.
+//
+// Built on the single-device entry points (rtmi_scene_create / rtmi_render_row_blocks_device); librccl is opened
+// at run time, and only when n > 1: a host that already carries an RCCL (torch does) shares its copy, and a
+// single-GPU host never loads the 570 MB library.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rtmi_internal.h"
+
+using namespace rtmi;
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+// one attempt per process; the result (or the reason it failed) is kept
+RcclApi& rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        a.handle = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD); // the copy the host process already has, if any
+        for (size_t i = 0; !a.handle && i < sizeof(names) / sizeof(names[0]); ++i) a.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!a.handle) {
+            const char* e = dlerror();
+            a.error = std::string("cannot load librccl: ") + (e ? e : "?");
+            return a;
+        }
+        auto sym = [&](const char* n) {
+            void* p = dlsym(a.handle, n);
+            if (!p && a.error.empty()) a.error = std::string("librccl lacks ") + n;
+            return p;
+        };
+        a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(sym("ncclCommInitAll"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+        a.Gather = reinterpret_cast<decltype(a.Gather)>(sym("ncclGather"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        return a;
+    }();
+    return api;
+}
+
+// gathered rows are rank-major ([rank][max_rows]); image row y sits at gathered row index[y]
+__global__ void __launch_bounds__(256) rtmi_deinterleave_kernel(const float* __restrict__ g_rgb, const uint32_t* __restrict__ g_rgba,
+                                                                const uint32_t* __restrict__ index, uint32_t W, uint32_t H,
+                                                                float* __restrict__ rgb, uint32_t* __restrict__ rgba) {
+    const uint32_t y = blockIdx.y;
+    if (y >= H) return;
+    const size_t src = (size_t)index[y] * W, dst = (size_t)y * W;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < W; x += gridDim.x * blockDim.x) {
+        rgba[dst + x] = g_rgba[src + x];
+        rgb[3 * (dst + x) + 0] = g_rgb[3 * (src + x) + 0];
+        rgb[3 * (dst + x) + 1] = g_rgb[3 * (src + x) + 1];
+        rgb[3 * (dst + x) + 2] = g_rgb[3 * (src + x) + 2];
+    }
+}
+
+struct Shard {
+    uint32_t y_first = 0, n_blocks = 0, rows = 0;
+};
+
+} // namespace
+
+struct rtmi_frame {
+    uint32_t n = 0, W = 0, H = 0, block_rows = 8, max_rows = 0;
+    std::vector<int> devices;
+    std::vector<rtmi_scene*> scenes;
+    std::vector<hipStream_t> streams;
+    std::vector<float*> d_rgb_slice;      // per device: max_rows * W * 3
+    std::vector<uint32_t*> d_rgba_slice;  // per device: max_rows * W
+    std::vector<Shard> shards;
+    std::vector<ncclComm_t> comms;        // empty when n == 1
+    // on devices[0]
+    float* d_rgb_gather = nullptr;        // n * max_rows * W * 3 (n > 1; otherwise the slice itself)
+    uint32_t* d_rgba_gather = nullptr;
+    float* d_rgb_frame = nullptr;         // H * W * 3, scanline order
+    uint32_t* d_rgba_frame = nullptr;
+    uint32_t* d_index = nullptr;          // H
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;
+    rtmi_frame_timing timing{};
+};
+
+namespace {
+
+#define HIPF(expr)                                                                           \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+            return e_ == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_HIP;                  \
+        }                                                                                    \
+    } while (0)
+#define NCCLF(expr)                                                                          \
+    do {                                                                                     \
+        ncclResult_t r_ = (expr);                                                            \
+        if (r_ != ncclSuccess) {                                                             \
+            set_error(std::string(#expr) + ": " + rccl_api().GetErrorString(r_));           \
+            return RTMI_ERR_RCCL;                                                            \
+        }                                                                                    \
+    } while (0)
+
+struct PrevDevice {
+    int prev = -1;
+    PrevDevice() {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            prev = -1;
+            (void)hipGetLastError();
+        }
+    }
+    ~PrevDevice() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+void free_frame(rtmi_frame* f) {
+    if (!f) return;
+    for (size_t i = 0; i < f->comms.size(); ++i) {
+        if (f->comms[i]) rccl_api().CommDestroy(f->comms[i]);
+    }
+    for (uint32_t i = 0; i < f->devices.size(); ++i) {
+        (void)hipSetDevice(f->devices[i]);
+        if (i < f->scenes.size() && f->scenes[i]) rtmi_scene_destroy(f->scenes[i]);
+        if (i < f->d_rgb_slice.size()) (void)hipFree(f->d_rgb_slice[i]);
+        if (i < f->d_rgba_slice.size()) (void)hipFree(f->d_rgba_slice[i]);
+        if (i < f->streams.size() && f->streams[i]) (void)hipStreamDestroy(f->streams[i]);
+    }
+    if (!f->devices.empty()) {
+        (void)hipSetDevice(f->devices[0]);
+        if (f->n > 1) {
+            (void)hipFree(f->d_rgb_gather);
+            (void)hipFree(f->d_rgba_gather);
+        }
+        (void)hipFree(f->d_rgb_frame);
+        (void)hipFree(f->d_rgba_frame);
+        (void)hipFree(f->d_index);
+        if (f->ev_g0) (void)hipEventDestroy(f->ev_g0);
+        if (f->ev_g1) (void)hipEventDestroy(f->ev_g1);
+    }
+    delete f;
+}
+
+int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
+                      const rtmi_material* materials, uint32_t n_materials, const rtmi_scene_options* options,
+                      const int32_t* devices, uint32_t n, uint32_t block_rows, rtmi_frame*& f) {
+    int n_visible = 0;
+    HIPF(hipGetDeviceCount(&n_visible));
+    for (uint32_t i = 0; i < n; ++i) {
+        if (devices[i] < 0 || devices[i] >= n_visible) {
+            set_error("rtmi_frame_create: device ordinal outside the visible devices");
+            return RTMI_ERR_BAD_ARG;
+        }
+        for (uint32_t j = 0; j < i; ++j) {
+            if (devices[j] == devices[i]) {
+                set_error("rtmi_frame_create: the same device listed twice (RCCL needs one rank per device)");
+                return RTMI_ERR_BAD_ARG;
+            }
+        }
+    }
+    f = new (std::nothrow) rtmi_frame();
+    if (!f) {
+        set_error("rtmi_frame_create: out of host memory");
+        return RTMI_ERR_OOM;
+    }
+    f->n = n;
+    f->W = camera->img_width;
+    f->H = camera->img_height;
+    f->block_rows = block_rows ? block_rows : 8u;
+    f->devices.assign(devices, devices + n);
+    f->scenes.assign(n, nullptr);
+    f->streams.assign(n, nullptr);
+    f->d_rgb_slice.assign(n, nullptr);
+    f->d_rgba_slice.assign(n, nullptr);
+    f->shards.assign(n, Shard{});
+
+    // interleaved row blocks: block b -> device b mod n; every device renders into a dense slice of max_rows rows
+    const uint32_t H = f->H, W = f->W, B = f->block_rows;
+    const uint32_t n_blocks_total = (H + B - 1) / B;
+    std::vector<uint32_t> index(H, 0u);
+    for (uint32_t r = 0; r < n; ++r) {
+        Shard& sh = f->shards[r];
+        sh.y_first = r * B;
+        sh.n_blocks = n_blocks_total > r ? (n_blocks_total - r + n - 1) / n : 0u;
+        for (uint32_t k = 0; k < sh.n_blocks; ++k) sh.rows += std::min(B, H - (r + k * n) * B);
+        f->max_rows = std::max(f->max_rows, sh.rows);
+    }
+    for (uint32_t y = 0; y < H; ++y) {
+        const uint32_t b = y / B, r = b % n, k = b / n;
+        index[y] = r * f->max_rows + k * B + (y - b * B);
+    }
+
+    rtmi_scene_options opt{};
+    opt.device = -1;
+    if (options) std::memcpy(&opt, options, std::min<size_t>(sizeof(opt), options->struct_size));
+    opt.struct_size = sizeof(opt);
+    const size_t slice_px = (size_t)std::max(1u, f->max_rows) * std::max(1u, W);
+    for (uint32_t i = 0; i < n; ++i) {
+        HIPF(hipSetDevice(devices[i]));
+        opt.device = devices[i];
+        const int rc = rtmi_scene_create(camera, objects, n_objects, materials, n_materials, &opt, &f->scenes[i]);
+        if (rc != RTMI_OK) return rc;
+        HIPF(hipStreamCreateWithFlags(&f->streams[i], hipStreamNonBlocking));
+        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgb_slice[i]), slice_px * 3 * sizeof(float)));
+        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgba_slice[i]), slice_px * sizeof(uint32_t)));
+        HIPF(hipMemset(f->d_rgb_slice[i], 0, slice_px * 3 * sizeof(float)));
+        HIPF(hipMemset(f->d_rgba_slice[i], 0, slice_px * sizeof(uint32_t)));
+    }
+    HIPF(hipSetDevice(devices[0]));
+    const size_t frame_px = (size_t)std::max(1u, H) * std::max(1u, W);
+    HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgb_frame), frame_px * 3 * sizeof(float)));
+    HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgba_frame), frame_px * sizeof(uint32_t)));
+    HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_index), std::max<size_t>(1, H) * sizeof(uint32_t)));
+    if (H) HIPF(hipMemcpy(f->d_index, index.data(), H * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPF(hipEventCreate(&f->ev_g0));
+    HIPF(hipEventCreate(&f->ev_g1));
+    if (n > 1) {
+        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgb_gather), slice_px * n * 3 * sizeof(float)));
+        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgba_gather), slice_px * n * sizeof(uint32_t)));
+        RcclApi& api = rccl_api();
+        if (!api.error.empty() || !api.Gather) {
+            set_error("rtmi_frame_create: " + (api.error.empty() ? std::string("librccl unusable") : api.error));
+            return RTMI_ERR_RCCL;
+        }
+        f->comms.assign(n, nullptr);
+        NCCLF(api.CommInitAll(f->comms.data(), (int)n, f->devices.data()));
+    } else {
+        f->d_rgb_gather = f->d_rgb_slice[0];
+        f->d_rgba_gather = f->d_rgba_slice[0];
+    }
+    return RTMI_OK;
+}
+
+int frame_render_impl(rtmi_frame* f, uint64_t seed) {
+    const uint32_t n = f->n, W = f->W, H = f->H;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (W == 0 || H == 0) return RTMI_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Shard& sh = f->shards[i];
+        if (!sh.n_blocks) continue;
+        const int rc = rtmi_render_row_blocks_device(f->scenes[i], sh.y_first, f->block_rows, n, sh.n_blocks, seed,
+                                                     f->d_rgb_slice[i], f->d_rgba_slice[i], f->streams[i]);
+        if (rc != RTMI_OK) return rc;
+    }
+    HIPF(hipSetDevice(f->devices[0]));
+    HIPF(hipEventRecord(f->ev_g0, f->streams[0]));
+    if (n > 1) {
+        // ONE gather of the dense slices to devices[0]: every rank's call sits in one group, on its own stream, behind its
+        // own kernels
+        RcclApi& api = rccl_api();
+        const size_t slice_px = (size_t)f->max_rows * W;
+        NCCLF(api.GroupStart());
+        for (uint32_t i = 0; i < n; ++i) {
+            NCCLF(api.Gather(f->d_rgb_slice[i], f->d_rgb_gather, slice_px * 3, ncclFloat32, 0, f->comms[i], f->streams[i]));
+            NCCLF(api.Gather(f->d_rgba_slice[i], f->d_rgba_gather, slice_px, ncclUint32, 0, f->comms[i], f->streams[i]));
+        }
+        NCCLF(api.GroupEnd());
+        HIPF(hipSetDevice(f->devices[0]));
+    }
+    rtmi_deinterleave_kernel<<<dim3((W + 255u) / 256u, H), dim3(256), 0, f->streams[0]>>>(
+        f->d_rgb_gather, f->d_rgba_gather, f->d_index, W, H, f->d_rgb_frame, f->d_rgba_frame);
+    HIPF(hipGetLastError());
+    HIPF(hipEventRecord(f->ev_g1, f->streams[0]));
+    for (uint32_t i = 0; i < n; ++i) {
+        HIPF(hipSetDevice(f->devices[i]));
+        HIPF(hipStreamSynchronize(f->streams[i]));
+    }
+    f->timing.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    HIPF(hipSetDevice(f->devices[0]));
+    HIPF(hipEventElapsedTime(&f->timing.gather_ms, f->ev_g0, f->ev_g1));
+    for (uint32_t i = 0; i < n && i < 16u; ++i) {
+        f->timing.kernel_ms[i] = 0.0f;
+        if (f->shards[i].n_blocks) {
+            const int rc = rtmi_scene_last_kernel_ms(f->scenes[i], &f->timing.kernel_ms[i]);
+            if (rc != RTMI_OK) return rc;
+        }
+    }
+    return RTMI_OK;
+}
+
+template <class F>
+int guarded(const char* where, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try { set_error(std::string(where) + ": out of host memory"); } catch (...) {}
+        return RTMI_ERR_OOM;
+    } catch (...) {
+        try { set_error(std::string(where) + ": unexpected exception"); } catch (...) {}
+        return RTMI_ERR_INTERNAL;
+    }
+}
+
+} // namespace
+
+extern "C" int rtmi_frame_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
+                                 const rtmi_material* materials, uint32_t n_materials, const rtmi_scene_options* options,
+                                 const int32_t* devices, uint32_t n_devices, uint32_t block_rows, rtmi_frame** out) {
+    if (!camera || !out || !devices || n_devices == 0 || n_devices > 16 || (n_objects && !objects) ||
+        (n_materials && !materials)) {
+        try { set_error("rtmi_frame_create: null argument or device count outside 1..16"); } catch (...) {}
+        return RTMI_ERR_BAD_ARG;
+    }
+    *out = nullptr;
+    PrevDevice guard;
+    rtmi_frame* f = nullptr;
+    const int rc = guarded("rtmi_frame_create", [&] {
+        return frame_create_impl(camera, objects, n_objects, materials, n_materials, options, devices, n_devices,
+                                 block_rows, f);
+    });
+    if (rc != RTMI_OK) {
+        // keep the message of the failure, not of the clean-up
+        std::string msg;
+        try { msg = rtmi_last_error(); } catch (...) {}
+        free_frame(f);
+        try { set_error(msg); } catch (...) {}
+        return rc;
+    }
+    *out = f;
+    return RTMI_OK;
+}
+
+extern "C" void rtmi_frame_destroy(rtmi_frame* frame) {
+    PrevDevice guard;
+    free_frame(frame);
+}
+
+extern "C" int rtmi_frame_render_device(rtmi_frame* f, uint64_t seed, void** d_rgb_linear, void** d_rgba8) {
+    if (!f) {
+        try { set_error("rtmi_frame_render_device: null frame"); } catch (...) {}
+        return RTMI_ERR_BAD_ARG;
+    }
+    PrevDevice guard;
+    const int rc = guarded("rtmi_frame_render_device", [&] { return frame_render_impl(f, seed); });
+    if (rc != RTMI_OK) return rc;
+    if (d_rgb_linear) *d_rgb_linear = f->d_rgb_frame;
+    if (d_rgba8) *d_rgba8 = f->d_rgba_frame;
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_frame_render(rtmi_frame* f, uint64_t seed, float* rgb_linear_out, uint32_t* rgba8_out) {
+    if (!f) {
+        try { set_error("rtmi_frame_render: null frame"); } catch (...) {}
+        return RTMI_ERR_BAD_ARG;
+    }
+    PrevDevice guard;
+    return guarded("rtmi_frame_render", [&]() -> int {
+        const int rc = frame_render_impl(f, seed);
+        if (rc != RTMI_OK) return rc;
+        const size_t px = (size_t)f->W * f->H;
+        if (!px) return RTMI_OK;
+        HIPF(hipSetDevice(f->devices[0]));
+        if (rgb_linear_out) HIPF(hipMemcpy(rgb_linear_out, f->d_rgb_frame, px * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (rgba8_out) HIPF(hipMemcpy(rgba8_out, f->d_rgba_frame, px * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return RTMI_OK;
+    });
+}
+
+extern "C" int rtmi_frame_get_timing(const rtmi_frame* f, rtmi_frame_timing* out) {
+    if (!f || !out) {
+        try { set_error("rtmi_frame_get_timing: null argument"); } catch (...) {}
+        return RTMI_ERR_BAD_ARG;
+    }
+    *out = f->timing;
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_frame_rccl_ranks(const rtmi_frame* f, uint32_t* n_out) {
+    if (!f || !n_out) {
+        try { set_error("rtmi_frame_rccl_ranks: null argument"); } catch (...) {}
+        return RTMI_ERR_BAD_ARG;
+    }
+    *n_out = (uint32_t)f->comms.size();
+    return RTMI_OK;
+}

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <random>
 
 #include "rtmi_internal.h"
@@ -520,8 +521,25 @@ extern "C" int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, ui
         set_error("rtmi_bvh_build: null objects");
         return RTMI_ERR_BAD_ARG;
     }
+    for (uint32_t i = 0; i < n_objects; ++i) {
+        const rtmi_object& o = objects[i];
+        // a NaN centre breaks the strict weak ordering of the builder's sorts, an infinite radius gives NaN boxes
+        if (!std::isfinite(o.center[0]) || !std::isfinite(o.center[1]) || !std::isfinite(o.center[2]) ||
+            !std::isfinite(o.radius)) {
+            set_error("rtmi_bvh_build: object with a non-finite centre or radius");
+            return RTMI_ERR_BAD_ARG;
+        }
+    }
     Bvh bvh;
-    build_bvh(objects, n_objects, leaf_size ? leaf_size : 2u, bvh);
+    try {
+        build_bvh(objects, n_objects, leaf_size ? leaf_size : 2u, bvh);
+    } catch (const std::bad_alloc&) {
+        set_error("rtmi_bvh_build: out of host memory");
+        return RTMI_ERR_OOM;
+    } catch (...) {
+        set_error("rtmi_bvh_build: unexpected exception");
+        return RTMI_ERR_INTERNAL;
+    }
     if (n_nodes) *n_nodes = static_cast<uint32_t>(bvh.nodes.size());
     if (root_ref) *root_ref = bvh.root_ref;
     if (depth) *depth = bvh.depth;

@@ -474,6 +474,12 @@ struct RayTracingCore {
 
     // device side (owned): created by default_setup / setup, released by the destructor
     std::shared_ptr<rtmi_scene> rts_gpu_scene;
+    // more GPUs of the node (optional, attach_devices): one scene replica per listed device for workers that pull row
+    // blocks from a shared queue (the reference's N workers, main.cc:608-712), and one rtmi_frame for whole frames
+    // (interleaved row-block shards + one RCCL gather inside the library)
+    std::vector<std::shared_ptr<rtmi_scene>> rts_gpu_replicas;
+    std::shared_ptr<rtmi_frame> rts_gpu_frame;
+    rtmi_camera rts_camera_pod{}; // the 14 fields above as the C-ABI record
 
     // RayTracingCore::default_setup(), core.cc:171-216: loads data/config/world.config.json relative to the CWD.
     static std::shared_ptr<RayTracingCore> default_setup(uint32_t mt_seed = 12345,
@@ -519,7 +525,47 @@ struct RayTracingCore {
                                         static_cast<uint32_t>(core->rts_materials.size()), options, &scene),
                       "rtmi_scene_create");
         core->rts_gpu_scene = std::shared_ptr<rtmi_scene>(scene, rtmi_scene_destroy);
+        core->rts_camera_pod = cam;
         return core;
+    }
+
+    // Replicates the scene on `devices` (HIP ordinals).  Returns an rtmi_status; nothing is attached on failure.
+    int attach_devices(const std::vector<int32_t>& devices, uint32_t block_rows = 8,
+                       const rtmi_scene_options* options = nullptr) {
+        std::vector<std::shared_ptr<rtmi_scene>> replicas;
+        rtmi_scene_options opt{};
+        if (options) opt = *options;
+        opt.struct_size = sizeof(opt);
+        const auto* objs = reinterpret_cast<const rtmi_object*>(rts_world.data());
+        const auto* mats = reinterpret_cast<const rtmi_material*>(rts_materials.data());
+        const auto n_objs = static_cast<uint32_t>(rts_world.size()), n_mats = static_cast<uint32_t>(rts_materials.size());
+        for (const int32_t d : devices) {
+            opt.device = d;
+            rtmi_scene* scene = nullptr;
+            const int rc = rtmi_scene_create(&rts_camera_pod, objs, n_objs, mats, n_mats, &opt, &scene);
+            if (rc != RTMI_OK) return rc;
+            replicas.emplace_back(scene, rtmi_scene_destroy);
+        }
+        rtmi_frame* frame = nullptr;
+        const int rc = rtmi_frame_create(&rts_camera_pod, objs, n_objs, mats, n_mats, options, devices.data(),
+                                         static_cast<uint32_t>(devices.size()), block_rows, &frame);
+        if (rc != RTMI_OK) return rc;
+        rts_gpu_replicas = std::move(replicas);
+        rts_gpu_frame = std::shared_ptr<rtmi_frame>(frame, rtmi_frame_destroy);
+        return RTMI_OK;
+    }
+
+    // The whole frame on all attached devices in one call (rtmi_frame_render): scanline order, as raytrace_rows.
+    int raytrace_frame(uint64_t seed, RGBAColor* rgba, float* rgb_linear = nullptr) const noexcept {
+        if (!rts_gpu_frame) return raytrace_rows(0, rts_img_height, seed, rgba, rgb_linear);
+        return rtmi_frame_render(rts_gpu_frame.get(), seed, rgb_linear, reinterpret_cast<uint32_t*>(rgba));
+    }
+
+    // raytrace_rows on one of the attached replicas (worker w of a multi-GPU job system)
+    int raytrace_rows_on(size_t replica, uint32_t y0, uint32_t y1, uint64_t seed, RGBAColor* rgba,
+                         float* rgb_linear = nullptr) const noexcept {
+        if (replica >= rts_gpu_replicas.size()) return RTMI_ERR_BAD_ARG;
+        return rtmi_render_rows(rts_gpu_replicas[replica].get(), y0, y1, seed, rgb_linear, reinterpret_cast<uint32_t*>(rgba));
     }
 
     // Replaces the per-pixel loop over RayTracingCore::raytrace_pixel (core.cc:259-265, called from

@@ -8,7 +8,8 @@
 //                             over a host-side buffer of that layout (the GL object itself stays in the reference)
 //   RayTracer                 same public surface as the reference's class (src/main.cc:526-585): create / update /
 //                             shutdown / pixels_count / pixels_raytraced / image_size / render_time.  One GPU worker
-//                             thread replaces the N CPU workers: it pops shuffled ROW BLOCKS instead of 8x8 tiles
+//                             thread per attached device (RayTracingCore::attach_devices; one worker on the core's own
+//                             scene otherwise) replaces the N CPU workers: they pop shuffled ROW BLOCKS instead of 8x8 tiles
 //                             (main.cc:615-633), renders each with RayTracingCore::raytrace_rows and posts the finished
 //                             block; update() drains a bounded number of blocks per frame into write_pixel, exactly where
 //                             the reference drains its ZeroMQ inproc mailboxes (main.cc:733-774).
@@ -114,27 +115,41 @@ public:
         std::shuffle(blocks.begin(), blocks.end(), shuffler);
         Shared* st = _state.get();
         std::shared_ptr<RayTracingCore> c = _core;
-        _worker = std::thread([st, c, blocks = std::move(blocks), frame_seed]() {
-            for (const auto& [y0, y1] : blocks) { // RayTracingWorker::worker_loop, main.cc:443-505
-                if (st->quit.load()) break;       // ThreadQuitMessage, main.cc:776-782
-                RowBlock rb{y0, y1, std::vector<RGBAColor>(size_t(y1 - y0) * c->rts_img_width)};
-                if (c->raytrace_rows(y0, y1, frame_seed, rb.pixels.data()) != RTMI_OK) {
-                    st->failed.store(true); // setup/launch failures end the worker, as in main.cc:685-706
-                    break;
+        st->blocks = std::move(blocks);
+        // one worker per attached GPU, all pulling from the same shuffled queue (MonkaGigaQueue::pop_pkg, main.cc:413-421)
+        const size_t n_workers = std::max<size_t>(1, c->rts_gpu_replicas.size());
+        st->live_workers.store(static_cast<uint32_t>(n_workers));
+        for (size_t w = 0; w < n_workers; ++w) {
+            _workers.emplace_back([st, c, w, frame_seed]() {
+                for (;;) { // RayTracingWorker::worker_loop, main.cc:443-505
+                    if (st->quit.load()) break; // ThreadQuitMessage, main.cc:776-782
+                    const size_t i = st->next_block.fetch_add(1);
+                    if (i >= st->blocks.size()) break;
+                    const auto [y0, y1] = st->blocks[i];
+                    RowBlock rb{y0, y1, std::vector<RGBAColor>(size_t(y1 - y0) * c->rts_img_width)};
+                    const int rc = c->rts_gpu_replicas.empty() ? c->raytrace_rows(y0, y1, frame_seed, rb.pixels.data())
+                                                               : c->raytrace_rows_on(w, y0, y1, frame_seed, rb.pixels.data());
+                    if (rc != RTMI_OK) {
+                        st->failed.store(true); // setup/launch failures end the worker, as in main.cc:685-706
+                        break;
+                    }
+                    st->pixels_processed += (y1 - y0) * c->rts_img_width; // g_pixels_processed, main.cc:516
+                    std::lock_guard<std::mutex> lock(st->mu);
+                    st->mailbox.push_back(std::move(rb));
                 }
-                st->pixels_processed += (y1 - y0) * c->rts_img_width; // g_pixels_processed, main.cc:516
-                std::lock_guard<std::mutex> lock(st->mu);
-                st->mailbox.push_back(std::move(rb));
-            }
-            st->done.store(true);
-        });
+                if (st->live_workers.fetch_sub(1) == 1) st->done.store(true);
+            });
+        }
     }
     RayTracer(RayTracer&&) = default;
     RayTracer(const RayTracer&) = delete;
     ~RayTracer() {
         if (_state) _state->quit.store(true);
-        if (_worker.joinable()) _worker.join();
+        for (auto& w : _workers) {
+            if (w.joinable()) w.join();
+        }
     }
+    size_t worker_count() const noexcept { return _workers.size(); }
 
     // RayTracer::update, main.cc:733-774: drain what the worker has posted (bounded per call) into the display.
     template <typename Display>
@@ -175,10 +190,13 @@ private:
         std::deque<RowBlock> mailbox; // stands in for the ZMQ_CHANNEL inproc pair (main.cc:642-712)
         std::atomic<bool> quit{false}, done{false}, failed{false};
         std::atomic<uint32_t> pixels_processed{0};
+        std::vector<std::pair<uint32_t, uint32_t>> blocks; // the shuffled work packages, read-only once the workers run
+        std::atomic<size_t> next_block{0};
+        std::atomic<uint32_t> live_workers{0};
     };
     std::shared_ptr<RayTracingCore> _core;
     std::unique_ptr<Shared> _state;
-    std::thread _worker;
+    std::vector<std::thread> _workers;
     uint32_t _max_blocks;
     uint32_t _pixels_raytraced{};
     std::chrono::time_point<std::chrono::high_resolution_clock> _start_timepoint{

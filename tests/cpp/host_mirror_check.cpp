@@ -4,6 +4,9 @@
 //   host_mirror_check display <surface_w> <surface_h> <img_w> <img_h> <out.bin>  -> write_pixel mapping (no GPU needed)
 //   host_mirror_check stream <world.config.json> <seed> <rseed> <surface_w> <surface_h> <out.bin> <out.ppm>
 //                            -> RayTracer (job-system adapter) streaming row blocks into the display contract on the GPU
+//   host_mirror_check frame  <world.config.json> <seed> <rseed> <out.bin> [n_devices]
+//                            -> attach_devices({0..n-1}) + raytrace_frame (rtmi_frame_*: shards + RCCL gather) and the
+//                               multi-worker RayTracer; must equal raytrace_rows of the single scene
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -77,6 +80,49 @@ int main(int argc, char** argv) {
             std::fwrite(rgb.data(), sizeof(float), rgb.size(), f);
             std::fwrite(rgba.data(), sizeof(RGBAColor), rgba.size(), f);
             std::fclose(f);
+            return 0;
+        }
+        if (mode == "frame" && argc >= 6) {
+            auto core = RayTracingCore::setup(wd, seed);
+            const uint64_t rseed = std::strtoull(argv[4], nullptr, 10);
+            const int n_dev = argc >= 7 ? std::atoi(argv[6]) : 1;
+            std::vector<int32_t> devices;
+            for (int d = 0; d < n_dev; ++d) devices.push_back(d);
+            const size_t n = size_t(core->rts_img_width) * core->rts_img_height;
+            std::vector<RGBAColor> want(n), got(n);
+            std::vector<float> want_rgb(n * 3), got_rgb(n * 3);
+            if (core->raytrace_rows(0, core->rts_img_height, rseed, want.data(), want_rgb.data()) != RTMI_OK) return 4;
+            if (core->attach_devices(devices, 8) != RTMI_OK) {
+                std::fprintf(stderr, "attach_devices: %s\n", rtmi_last_error());
+                return 5;
+            }
+            if (core->raytrace_frame(rseed, got.data(), got_rgb.data()) != RTMI_OK) {
+                std::fprintf(stderr, "raytrace_frame: %s\n", rtmi_last_error());
+                return 6;
+            }
+            if (std::memcmp(want.data(), got.data(), n * sizeof(RGBAColor)) != 0) return 7;
+            if (std::memcmp(want_rgb.data(), got_rgb.data(), n * 3 * sizeof(float)) != 0) return 7;
+            // the job-system adapter with one worker per attached device
+            RayTracedImageTarget target(core->rts_img_width, core->rts_img_height, core->rts_img_width, core->rts_img_height);
+            auto tracer = RayTracer::create(core, rseed, 8, 64);
+            if (!tracer || tracer->worker_count() != devices.size()) return 8;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (tracer->pixels_raytraced() < tracer->pixels_count()) {
+                tracer->update(&target);
+                if (tracer->worker_failed()) return 9;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return 10;
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            for (uint32_t y = 0; y < core->rts_img_height; ++y)
+                for (uint32_t x = 0; x < core->rts_img_width; ++x)
+                    if (target.ssbo()->rti_pixels[size_t(core->rts_img_height - 1 - y) * core->rts_img_width + x].color !=
+                        want[size_t(y) * core->rts_img_width + x].color)
+                        return 11;
+            FILE* f = std::fopen(argv[5], "wb");
+            if (!f) return 8;
+            std::fwrite(got.data(), sizeof(RGBAColor), got.size(), f);
+            std::fclose(f);
+            std::printf("frame ok devices %d\n", n_dev);
             return 0;
         }
         if (mode == "stream" && argc >= 9) {

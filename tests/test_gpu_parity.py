@@ -56,31 +56,27 @@ def gpu(pkg):
 # ---------------------------------------------------------------------------------------------------------------
 # golden fixtures and oracle parity at oracle-sized problems
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("defer", ["auto", "1"])  # auto: launches this small keep the deferred-path queue off
-def test_golden_rtow_counter_frame(pkg, gpu, monkeypatch, defer):
-    if defer != "auto":
-        monkeypatch.setenv("RTMI_DEFER", defer)
+@pytest.mark.parametrize("defer", [0, 1])  # 0 = auto: launches this small keep the deferred-path queue off
+def test_golden_rtow_counter_frame(pkg, gpu, defer):
     g = np.load(os.path.join(GOLDEN, "rtow_counter_128x72x16.npz"))
     sc = np.load(os.path.join(GOLDEN, "rtow_scene_seed12345.npz"))
     cp = json.loads(str(g["camera"]))
     cam = pkg.camera_setup(pkg.camera_params(**cp))
     for accel, _ in _both(pkg):
-        with pkg.Scene(cam, sc["objects"], sc["materials"], accel=accel) as s:
+        with pkg.Scene(cam, sc["objects"], sc["materials"], accel=accel, tuning=dict(defer_mode=defer)) as s:
             rgb, rgba = s.render_rows(0, cam.img_height, int(g["seed"]))
         _assert_frames_equal(rgb, g["rgb"])
         assert np.array_equal(rgba, g["rgba"])
 
 
-@pytest.mark.parametrize("defer", ["auto", "1"])
-def test_golden_cornell_deep_bounce(pkg, gpu, monkeypatch, defer):
+@pytest.mark.parametrize("defer", [0, 1])
+def test_golden_cornell_deep_bounce(pkg, gpu, defer):
     """config 5 shape: enclosed box, 200 bounces."""
-    if defer != "auto":
-        monkeypatch.setenv("RTMI_DEFER", defer)
     g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
     cp = json.loads(str(g["camera"]))
     cam = pkg.camera_setup(pkg.camera_params(**cp))
     for accel, _ in _both(pkg):
-        with pkg.Scene(cam, g["objects"], g["materials"], accel=accel) as s:
+        with pkg.Scene(cam, g["objects"], g["materials"], accel=accel, tuning=dict(defer_mode=defer)) as s:
             rgb, rgba = s.render_rows(0, cam.img_height, int(g["seed"]))
         _assert_frames_equal(rgb, g["rgb"])
         assert np.array_equal(rgba, g["rgba"])
@@ -137,36 +133,31 @@ def test_random_spheres_mixed_radii(pkg, ob, gpu):
         _assert_frames_equal(rgb, want)
 
 
-def test_hbm_resident_scene_variant(pkg, ob, rtow, gpu, monkeypatch):
+def test_hbm_resident_scene_variant(pkg, ob, rtow, gpu):
     """Scenes that do not fit LDS are traversed out of HBM (config 4 path); forced here on the RTOW scene so that the
     same frame is checked through both memory layouts."""
     kw = dict(image_width=96, samples_per_pixel=8, max_depth=50)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
     want, want8 = ob.render_rect_counter(ocam, *rtow, 12, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
-    monkeypatch.setenv("RTMI_FORCE_BIG", "1")
     for accel, _ in _both(pkg):
-        with pkg.Scene(cam, *rtow, accel=accel) as s:
+        with pkg.Scene(cam, *rtow, accel=accel, tuning=dict(force_hbm_scene=1)) as s:
             rgb, rgba = s.render_rows(0, cam.img_height, 12)
         _assert_frames_equal(rgb, want)
         assert np.array_equal(rgba, want8)
 
 
-def test_scheduling_knobs_do_not_change_the_image(pkg, ob, rtow, gpu, monkeypatch):
+def test_scheduling_knobs_do_not_change_the_image(pkg, ob, rtow, gpu):
     """Sample-chunk work items, the deferred-path queue (also when it overflows), launch geometry and the traversal
     exit threshold are scheduling decisions: every combination yields the oracle's frame bit for bit."""
     kw = dict(image_width=128, samples_per_pixel=96, max_depth=50)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
     want, want8 = ob.render_rect_counter(ocam, *rtow, 44, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
-    for env in (dict(RTMI_CHUNK="0"), dict(RTMI_CHUNK="16", RTMI_DEFER="0"), dict(RTMI_CHUNK="16", RTMI_DEFER="1"),
-                dict(RTMI_CHUNK="32", RTMI_DEFER="1", RTMI_DEFER_CAP="64"), dict(RTMI_CHUNK="40", RTMI_BLOCK="256", RTMI_WAIT_THRESH="20"),
-                dict(RTMI_BLOCKS_PER_CU="1", RTMI_WAIT_THRESH="64", RTMI_TOPDOWN="1")):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True) as s:
+    for env in (dict(chunk_samples=-1), dict(chunk_samples=16, defer_mode=-1), dict(chunk_samples=16, defer_mode=1),
+                dict(chunk_samples=32, defer_mode=1, defer_cap=64), dict(chunk_samples=40, block_lanes=256, wait_thresh=20),
+                dict(blocks_per_cu=1, wait_thresh=64, top_down=1)):
+        with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=env) as s:
             rgb, rgba = s.render_rows(0, cam.img_height, 44)
             st = s.stats()
-        for k in env:
-            monkeypatch.delenv(k)
         _assert_frames_equal(rgb, want)
         assert np.array_equal(rgba, want8)
         assert st["samples"] == cam.img_width * cam.img_height * 96, env
@@ -263,7 +254,7 @@ def test_row_ranges_outputs_and_errors(pkg, ob, rtow, gpu):
     assert e.value.code == pkg.RTMI_ERR_BAD_ARG
 
 
-def test_ragged_image_sizes_chunks_and_block_strides(pkg, ob, gpu, monkeypatch):
+def test_ragged_image_sizes_chunks_and_block_strides(pkg, ob, gpu):
     """The work-item decode (tile, chunk, pixel, row block: multiply-shift divisions) over awkward geometries: widths and
     heights that are not multiples of the 8x8 tile, sample counts around the chunk size, strided row blocks."""
     torch = gpu
@@ -274,7 +265,7 @@ def test_ragged_image_sizes_chunks_and_block_strides(pkg, ob, gpu, monkeypatch):
         w = int(rng.choice([1, 2, 7, 8, 9, 15, 17, 31, 33, 63, 65, 100]))
         aspect = float(rng.choice([0.5, 1.0, 16.0 / 9.0, 3.0]))
         spp = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 33]))
-        chunk = str(int(rng.choice([0, 1, 2, 3, 4, 5, 8])))
+        chunk = int(rng.choice([-1, 1, 2, 3, 4, 5, 8]))
         depth = int(rng.integers(0, 9))
         if int(w / aspect) < 1:
             continue
@@ -282,9 +273,7 @@ def test_ragged_image_sizes_chunks_and_block_strides(pkg, ob, gpu, monkeypatch):
         cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
         W, H = cam.img_width, cam.img_height
         want, want8 = ob.render_rect_counter(ocam, objs, mats, case, 0, 0, W, H)
-        monkeypatch.setenv("RTMI_CHUNK", chunk)
-        monkeypatch.setenv("RTMI_DEFER", str(case & 1))
-        with pkg.Scene(cam, objs, mats) as s:
+        with pkg.Scene(cam, objs, mats, tuning=dict(chunk_samples=chunk, defer_mode=1 if case & 1 else -1)) as s:
             rgb, rgba = s.render_rows(0, H, case)
             _assert_frames_equal(rgb, want)
             assert np.array_equal(rgba, want8), (w, H, spp, chunk)
@@ -351,8 +340,52 @@ def test_device_pointer_entry_and_sharded_blocks(pkg, ob, rtow, gpu):
             assert np.array_equal(frame8, want8)
 
 
-def test_frames_larger_than_the_sample_buffer_are_rendered_in_bands(pkg, ob, rtow, gpu, monkeypatch):
-    """When the sample records of a call exceed RTMI_SAMPLE_BUF_MB the call is split into bands of rows (contiguous
+def test_multi_device_frame_entry_degenerate_one_device(pkg, ob, rtow, gpu):
+    """rtmi_frame_* with n = 1 (what one box offers): shard plan of one rank, no communicator, de-interleave kernel run
+    on the identity map -- the frame must be bit-equal to rtmi_render_rows and to the oracle; also with a block size that
+    does not divide the height, and the argument errors of the device list."""
+    torch = gpu
+    kw = dict(image_width=150, samples_per_pixel=6, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    W, H = cam.img_width, cam.img_height
+    want, want8 = ob.render_rect_counter(ocam, *rtow, 21, 0, 0, W, H, nthreads=8)
+    with pkg.Scene(cam, *rtow) as s:
+        ref, ref8 = s.render_rows(0, H, 21)
+    _assert_frames_equal(ref, want)
+    for block_rows in (8, 5, 0):
+        with pkg.Frame(cam, *rtow, devices=(0,), block_rows=block_rows) as f:
+            rgb, rgba = f.render(21)
+            assert f.rccl_ranks == 0
+            t = f.timing()
+            assert t["total_ms"] > 0.0 and t["kernel_ms"][0] > 0.0 and t["gather_ms"] >= 0.0
+            d_rgb, d_rgba = f.render_device(21)
+            assert d_rgb and d_rgba
+            torch.cuda.synchronize()
+        assert rgb.tobytes() == ref.tobytes() and np.array_equal(rgba, ref8)
+    n_dev = torch.cuda.device_count()
+    for devices in ((0, 0), (n_dev,), (-1,)):
+        with pytest.raises(pkg.RtmiError) as e:
+            pkg.Frame(cam, *rtow, devices=devices)
+        assert e.value.code == pkg.RTMI_ERR_BAD_ARG
+    assert torch.cuda.current_device() == 0  # every entry point restores the caller's device
+
+
+def test_images_wider_than_a_queue_record_can_address(pkg, ob, gpu):
+    """A deferred-path record packs the pixel as x | y << 16: a launch wider than 65535 pixels must keep its paths (the
+    deferral is a scheduling decision) -- 70000 x 8 with the queue forced on."""
+    objs, mats = three_spheres()
+    kw = dict(three_spheres_camera(), image_width=70000, aspect_ratio=70000.0 / 8.0, samples_per_pixel=8, max_depth=24)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    assert (cam.img_width, cam.img_height) == (70000, 8)
+    want, want8 = ob.render_rect_counter(ocam, objs, mats, 3, 0, 0, 70000, 8, nthreads=8)
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=dict(defer_mode=1, chunk_samples=2)) as s:
+        rgb, rgba = s.render_rows(0, 8, 3)
+    _assert_frames_equal(rgb, want)
+    assert np.array_equal(rgba, want8)
+
+
+def test_frames_larger_than_the_sample_buffer_are_rendered_in_bands(pkg, ob, rtow, gpu):
+    """When the sample records of a call exceed rtmi_tuning::sample_buf_mb the call is split into bands of rows (contiguous
     rows) or of whole row blocks (sharded call); the draw streams are keyed by the absolute pixel, so the frame is the
     oracle's, bit for bit, and rtmi_scene_last_kernel_ms brackets all bands."""
     torch = gpu
@@ -360,8 +393,8 @@ def test_frames_larger_than_the_sample_buffer_are_rendered_in_bands(pkg, ob, rto
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
     W, H = cam.img_width, cam.img_height
     want, want8 = ob.render_rect_counter(ocam, *rtow, 45, 0, 0, W, H, nthreads=8)
-    monkeypatch.setenv("RTMI_SAMPLE_BUF_MB", "1")  # 196 KB of records per row: 5 rows per band
-    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH) as s:
+    # 196 KB of records per row: 5 rows per band
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(sample_buf_mb=1)) as s:
         rgb, rgba = s.render_rows(0, H, 45)
         assert s.last_kernel_ms() > 0.0
         part, part8 = s.render_rows(7, 31, 45)  # a row range that is not a multiple of the band
@@ -369,9 +402,8 @@ def test_frames_larger_than_the_sample_buffer_are_rendered_in_bands(pkg, ob, rto
     assert np.array_equal(rgba, want8)
     _assert_frames_equal(part, want[7:31])
     assert np.array_equal(part8, want8[7:31])
-    monkeypatch.setenv("RTMI_SAMPLE_BUF_MB", "4")  # 21 rows: two 8-row blocks per band
     dev = torch.device("cuda", 0)
-    with pkg.Scene(cam, *rtow, device=0) as s:
+    with pkg.Scene(cam, *rtow, device=0, tuning=dict(sample_buf_mb=4)) as s:  # 21 rows: two 8-row blocks per band
         plan = pkg.RowShardPlan(H, 8, 2)
         parts = []
         for r in range(2):

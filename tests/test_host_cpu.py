@@ -84,6 +84,60 @@ def test_scene_create_argument_errors(pkg):
     pkg.lib().rtmi_scene_destroy(None)  # no-op
 
 
+@pytest.mark.parametrize("field,value", [("center", float("nan")), ("center", float("inf")), ("radius", float("nan")),
+                                         ("radius", float("inf"))])
+def test_non_finite_spheres_are_rejected(pkg, field, value):
+    """A NaN centre breaks the ordering of the BVH builder's sorts, an infinite radius gives NaN boxes the walk can never
+    enter while the linear scan still tests the sphere: both entry points refuse such objects, for either accel."""
+    cam = pkg.camera_setup(pkg.camera_params(image_width=64))
+    objs, mats = pkg.make_world_spheres(1)
+    bad = objs.copy()
+    if field == "center":
+        bad["center"][17][1] = value
+    else:
+        bad["radius"][17] = value
+    with pytest.raises(pkg.RtmiError) as e:
+        pkg.bvh_build(bad)
+    assert e.value.code == pkg.RTMI_ERR_BAD_ARG and "non-finite" in str(e.value)
+    for accel in (pkg.ACCEL_BVH, pkg.ACCEL_BRUTE):
+        with pytest.raises(pkg.RtmiError) as e:
+            pkg.Scene(cam, bad, mats, accel=accel)
+        assert e.value.code == pkg.RTMI_ERR_BAD_ARG and "non-finite" in str(e.value)
+
+
+def test_frame_create_argument_errors(pkg):
+    """rtmi_frame_create checks its device list before touching any device."""
+    cam = pkg.camera_setup(pkg.camera_params(image_width=64))
+    objs, mats = pkg.make_world_spheres(1)
+    L = pkg.lib()
+    h = C.c_void_p()
+    devs = (C.c_int32 * 2)(0, 0)
+    assert L.rtmi_frame_create(C.byref(cam), None, 0, None, 0, None, None, 1, 8, C.byref(h)) == pkg.RTMI_ERR_BAD_ARG
+    assert L.rtmi_frame_create(C.byref(cam), None, 0, None, 0, None, devs, 0, 8, C.byref(h)) == pkg.RTMI_ERR_BAD_ARG
+    assert L.rtmi_frame_create(C.byref(cam), None, 0, None, 0, None, devs, 17, 8, C.byref(h)) == pkg.RTMI_ERR_BAD_ARG
+    assert L.rtmi_frame_render(None, 0, None, None) == pkg.RTMI_ERR_BAD_ARG
+    assert L.rtmi_frame_get_timing(None, None) == pkg.RTMI_ERR_BAD_ARG
+    L.rtmi_frame_destroy(None)  # no-op
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(pkg.RtmiError) as e:
+            pkg.Frame(cam, objs, mats, devices=(0,))
+        assert e.value.code == pkg.RTMI_ERR_HIP  # no device: fails loudly, no fallback
+
+
+def test_tuning_struct_layout_and_unknown_knobs(pkg):
+    assert C.sizeof(pkg.Tuning) == 64 and C.sizeof(pkg.SceneOptions) == 40
+    with pytest.raises(KeyError):
+        pkg.make_tuning(no_such_knob=1)
+    header = open(os.path.join(ROOT, "include", "rtmi.h")).read()
+    body = header[header.index("typedef struct rtmi_tuning {"):header.index("} rtmi_tuning;")]
+    fields = re.findall(r"^\s+u?int32_t\s+([a-z_]+)(?:\[\d+\])?;", body, flags=re.M)
+    assert fields == [n for n, _ in pkg.Tuning._fields_]
+    # the library reads no environment variables
+    for src in ("rtmi_device.hip", "rtmi_host.cpp", "rtmi_frame.hip"):
+        assert "getenv" not in open(os.path.join(ROOT, "raytracing.cpp_amd", "csrc", src)).read()
+
+
 def _check_bvh(pkg, objs, leaf):
     b = pkg.bvh_build(objs, leaf)
     n = len(objs)

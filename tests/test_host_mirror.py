@@ -108,6 +108,23 @@ def test_default_setup_and_render_through_the_mirror(exe, ob, tmp_path):
     assert rgb.tobytes() == want.tobytes() and np.array_equal(rgba, want8)
 
 
+@pytest.mark.gpu
+def test_attached_devices_frame_and_multi_worker_tracer(exe, ob, tmp_path):
+    """RayTracingCore::attach_devices + raytrace_frame (rtmi_frame_*: row-block shards, gather, scanline order) and the
+    RayTracer with one worker per attached device, on the one GPU of the box (n = 1: no communicator); the program itself
+    checks both against raytrace_rows of the single scene, this test checks the frame against the oracle."""
+    cfg = str(tmp_path / "world.config.json")
+    _world_json(cfg, _camera(104, 4, 20))
+    out = str(tmp_path / "frame8.bin")
+    r = subprocess.run([exe, "frame", cfg, "12345", "78", out, "1"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    ocam = ob.camera_setup(ob.camera_params(image_width=104, samples_per_pixel=4, max_depth=20))
+    objs, mats = ob.make_world_spheres(12345, ob.world_def(), _fixed_from_json())
+    _, want8 = ob.render_rect_counter(ocam, objs, mats, 78, 0, 0, 104, ocam.img_height, nthreads=8)
+    got = np.frombuffer(open(out, "rb").read(), np.uint32).reshape(ocam.img_height, 104)
+    assert np.array_equal(got, want8)
+
+
 def _ssbo(path):
     raw = open(path, "rb").read()
     sw, sh = np.frombuffer(raw[:8], np.uint32)

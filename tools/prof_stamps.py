@@ -10,7 +10,7 @@ if "--build" in sys.argv:
     subprocess.run(cmd, check=True)
     print("built", prof_lib); sys.exit(0)
 pkg.LIB_PATH = prof_lib
-os.environ.setdefault("RTMI_WAIT_THRESH", "56")
+
 w, spp = int(sys.argv[1]), int(sys.argv[2])
 if len(sys.argv) > 3 and sys.argv[3] == "grid":  # BASELINE config 4: 100k spheres, scene in HBM
     from tests.scenes import big_grid

@@ -8,11 +8,14 @@ constexpr int kIters = 2048, kChains = 8;
 
 template <int OP>
 __global__ void __launch_bounds__(256) bench(uint32_t* out, uint32_t seed) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
     uint32_t v[kChains];
     float f[kChains];
+    f2 p[kChains];
     for (int c = 0; c < kChains; ++c) {
         v[c] = seed + threadIdx.x * 7u + c;
         f[c] = (float)v[c];
+        p[c] = f2{f[c], f[c] + 1.0f};
     }
     for (int i = 0; i < kIters; ++i) {
 #pragma unroll
@@ -29,10 +32,18 @@ __global__ void __launch_bounds__(256) bench(uint32_t* out, uint32_t seed) {
             if (OP == 5) asm volatile("v_mul_u32_u24 %0, %0, %0" : "+v"(v[c]));
             if (OP == 6) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[c]));
             if (OP == 7) asm volatile("v_sqrt_f32 %0, %0" : "+v"(f[c]));
+            if (OP == 8) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(p[c]));
+            if (OP == 9) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p[c]));
+            if (OP == 10) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(p[c]));
+            if (OP == 11) asm volatile("v_max3_f32 %0, %0, %0, %0" : "+v"(f[c]));
+            if (OP == 12) asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(v[c]));
+            if (OP == 13) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(f[c]));
+            if (OP == 14) asm volatile("v_mul_hi_u32_u24 %0, %0, %0" : "+v"(v[c]));
+            if (OP == 15) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(*(double*)&p[c]));
         }
     }
     uint32_t acc = 0;
-    for (int c = 0; c < kChains; ++c) acc ^= v[c] ^ __float_as_uint(f[c]);
+    for (int c = 0; c < kChains; ++c) acc ^= v[c] ^ __float_as_uint(f[c]) ^ __float_as_uint(p[c].x) ^ __float_as_uint(p[c].y);
     if (acc == 0x12345u) out[0] = acc;
 }
 
@@ -68,5 +79,13 @@ int main() {
     run<5>("v_mul_u32_u24", 0);
     run<6>("v_rcp_f32", 0);
     run<7>("v_sqrt_f32", 0);
+    run<8>("v_pk_fma_f32", 0);
+    run<9>("v_pk_mul_f32", 0);
+    run<10>("v_pk_add_f32", 0);
+    run<11>("v_max3_f32", 0);
+    run<12>("v_cndmask_b32", 0);
+    run<13>("v_mul_f32", 0);
+    run<14>("v_mul_hi_u32_u24", 0);
+    run<15>("v_fma_f64", 0);
     return 0;
 }
