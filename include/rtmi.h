@@ -115,7 +115,11 @@ typedef struct rtmi_tuning {
     uint32_t sample_buf_mb;     /* cap on the sample-record buffer in MiB (default 24576); larger calls run in row bands */
     uint32_t force_hbm_scene;   /* nonzero: leave the scene in HBM even when it fits LDS (the config-4 path) */
     uint32_t top_down;          /* nonzero: hand out tiles top row first instead of bottom row first */
-    uint32_t reserved[5];
+    uint32_t kernel;            /* BVH scenes: 0 = library default, 1 = round-based kernel, 2 = queue-scheduled kernel */
+    uint32_t wf_block_lanes;    /* queue-scheduled kernel: lanes per workgroup (default 1024: one workgroup per CU) */
+    uint32_t wf_slots;          /* its path slots per workgroup (default: as many as LDS holds, at most 2 per lane) */
+    uint32_t wf_refill;         /* idle lanes at which a traversing wave takes new rays (default 24) */
+    uint32_t reserved[1];
 } rtmi_tuning;
 
 typedef struct rtmi_scene_options {

@@ -18,8 +18,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "librtmi.so")
-CSRC = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_host.cpp", "rtmi_device.hip", "rtmi_frame.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "rtmi_internal.h"), os.path.join(_ROOT, "include", "rtmi.h")]
+CSRC = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_host.cpp", "rtmi_device.hip", "rtmi_wavefront.hip", "rtmi_frame.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "rtmi_internal.h"), os.path.join(_HERE, "csrc", "rtmi_kernel_common.h"),
+           os.path.join(_ROOT, "include", "rtmi.h")]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -74,7 +75,9 @@ class Tuning(C.Structure):  # rtmi_tuning: scheduling knobs, 0 = default; none o
     _fields_ = [("struct_size", C.c_uint32), ("block_lanes", C.c_uint32), ("blocks_per_cu", C.c_uint32),
                 ("wait_thresh", C.c_uint32), ("drain_wait_thresh", C.c_uint32), ("chunk_samples", C.c_int32),
                 ("defer_mode", C.c_int32), ("defer_cap", C.c_uint32), ("sample_buf_mb", C.c_uint32),
-                ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("kernel", C.c_uint32),
+                ("wf_block_lanes", C.c_uint32), ("wf_slots", C.c_uint32), ("wf_refill", C.c_uint32),
+                ("reserved", C.c_uint32 * 1)]
 
 
 class SceneOptions(C.Structure):

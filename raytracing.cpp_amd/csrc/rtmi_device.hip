@@ -41,291 +41,7 @@
 
 #include "rtmi_internal.h"
 
-using namespace rtmi;
-
-// Division by a launch-invariant 32-bit divisor (Granlund & Montgomery, PLDI'94, fig. 4.1): q = n / d for every
-// 32-bit n, five instructions instead of the ~40 of an integer division.
-struct FastDiv {
-    uint32_t m, sh1, sh2;
-};
-static FastDiv make_fastdiv(uint32_t d) {
-    FastDiv f{1u, 0u, 0u};
-    if (d == 0u) d = 1u;
-    uint32_t l = 0;
-    while ((1ull << l) < d) ++l; // ceil(log2 d)
-    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
-    f.sh1 = l < 1u ? l : 1u;
-    f.sh2 = l > 0u ? l - 1u : 0u;
-    return f;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// launch parameters (kernarg -> SGPRs)
-// ---------------------------------------------------------------------------------------------------------
-struct RtmiLaunch {
-    rtmi_camera cam;
-    // scene, global memory (staged into LDS by every workgroup)
-    const uint4* spheres;  // [n_slots] {cx, cy, cz, r*r} as bits
-    const uint4* aux;      // [n_slots] {object index, material handle, radius bits, MaterialKind of that handle}
-    const uint4* mats;     // [n_mats]  {p0, p1, p2, p3} (albedo + fuzz, or refraction index in p0); the kind rides in aux.w
-    const uint4* nodes;    // [n_nodes] 4 x uint4 per node (rtmi_bvh_node)
-    uint32_t n_slots, n_mats, n_nodes, root_ref;
-    uint32_t pre_leaf[4];     // leaves hanging off the top of the tree (the ground sphere): tested at segment set-up
-    uint32_t n_pre_leaves;    // root_ref == kNoWalk: they were the whole tree
-    float pad_classes[kMaxPadClasses][8];
-    uint32_t n_pad_classes;
-    float pad_eps, pad_floor;
-    // LDS carve-up (byte offsets)
-    uint32_t lds_spheres, lds_aux, lds_mats, lds_nodes, lds_stack, stack_depth, lds_att, lds_pool;
-    // image rows handled by this launch
-    uint32_t y_first, block_rows, block_stride, n_local_rows;
-    uint32_t tiles_x, tiles_y, n_work; // work index space = tiles * 64
-    FastDiv div_tiles_x, div_chunks, div_block_rows;
-    uint32_t top_down;
-    // sample-chunk split: a work item is `chunk` consecutive samples of one pixel; their colours go to sample_buf
-    // ([pixel][sample] float4) and rtmi_resolve_kernel adds them up in sample order.  n_chunks == 1: a lane owns
-    // the whole pixel and sums in registers.
-    uint32_t chunk, n_chunks;
-    float4* sample_buf;
-    // path deferral (needs the sample buffer): a path that turns out to bounce INSIDE an opaque sphere (back-face hit
-    // on a Lambertian/Metallic material -- fp32 self-intersection of the ground sphere traps 3 % of the samples for all
-    // 50 bounces, 39 % of all segments) is written to a compacted queue and finished by a second launch of this kernel
-    // (mode 1) whose lanes all walk such paths: 2-3 BVH steps per segment instead of idling next to 13-step walks.
-    // A scheduling decision only: both launches run the same arithmetic on the same (pixel, sample, draw) stream.
-    uint4* defer_buf;       // [defer_cap] records of 5 x uint4
-    uint32_t* defer_count;  // records appended (may overshoot defer_cap; clamp)
-    uint32_t defer_cap;
-    uint32_t mode;          // 0: primary launch, 1: drain launch (work items are queue records)
-    uint32_t wait_thresh;     // leave the traversal loop when this many lanes of a wave wait for shading
-    uint64_t seed;
-    float* out_rgb;
-    uint32_t* out_rgba;
-    uint32_t* work_counter;
-    uint32_t* att_stack; // [lane][maxdepth] {handle, count}: attenuation runs that did not fit LDS
-    unsigned long long* stats; // {samples, segments, sphere_tests, node_tests}
-};
-
-#define DEV static __device__ __forceinline__
-
-DEV uint32_t fdiv(uint32_t n, const FastDiv f) {
-    const uint32_t t1 = __umulhi(f.m, n);
-    return (t1 + ((n - t1) >> f.sh1)) >> f.sh2;
-}
-
-// In-kernel stamps (diagnostic build only, -DRTMI_PROF): s_memtime deltas per phase of the v1 kernel, summed per wave
-// into stats[8 + i].  Never compiled into the shipped library.
-#ifdef RTMI_PROF
-#define PF_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0, pf7 = 0, pf8 = 0, pf9 = 0, pf10 = 0, pf11 = 0, pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0, pl4 = 0, pl5 = 0, pl6 = 0, pl7 = 0;
-#define PF_MARK(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - pf_t; pf_t = n_; } while (0)
-#define PF_COUNT(acc) do { acc += 1; } while (0)
-#define PF_LANES(acc, mask) do { acc += (unsigned long long)__popcll(mask); } while (0)
-#else
-#define PF_DECL
-#define PF_MARK(acc) do { } while (0)
-#define PF_COUNT(acc) do { } while (0)
-#define PF_LANES(acc, mask) do { } while (0)
-#endif
-
-// ---------------------------------------------------------------------------------------------------------
-// vec3 with glm's published semantics (glm is an un-vendored dependency of the reference)
-// ---------------------------------------------------------------------------------------------------------
-struct V3 {
-    float x, y, z;
-};
-DEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
-DEV V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-DEV V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-DEV V3 vmul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
-DEV V3 vscale(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-DEV V3 vdivs(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
-DEV V3 vneg(V3 a) { return mk(-a.x, -a.y, -a.z); }
-DEV float vdot(V3 a, V3 b) { // glm::dot: t = a*b; t.x + t.y + t.z
-    const float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
-    return (tx + ty) + tz;
-}
-DEV V3 vnormalize(V3 v) { return vscale(v, 1.0f / __builtin_sqrtf(vdot(v, v))); } // v * inversesqrt(dot(v,v))
-DEV V3 vreflect(V3 I, V3 N) { return vsub(I, vscale(vscale(N, vdot(N, I)), 2.0f)); }
-DEV V3 vrefract(V3 I, V3 N, float eta) {
-    const float d = vdot(N, I);
-    const float k = 1.0f - eta * eta * (1.0f - d * d);
-    if (k >= 0.0f) return vsub(vscale(I, eta), vscale(N, eta * d + __builtin_sqrtf(k)));
-    return mk(0.0f, 0.0f, 0.0f);
-}
-DEV V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
-
-// ---------------------------------------------------------------------------------------------------------
-// counter RNG: draw #k of (seed, pixel, sample) = word (k & 3) of Philox4x32-10({k >> 2, sample, pixel, 0}, seed);
-// random_double() = u32 * 2^-32.  The affine maps of random.number.gen.hpp are exact in double for a 32-bit
-// draw, so the double -> float narrowing of the reference equals one int -> float conversion here.
-// ---------------------------------------------------------------------------------------------------------
-struct Rng { // per-lane stream position; no cached block: every consumer asks for the block it needs
-    uint32_t k, pixel, sample;
-};
-struct Blk {
-    uint32_t w0, w1, w2, w3;
-};
-
-DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, Blk& r) {
-#pragma unroll
-    for (int round = 0; round < 10; ++round) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    r.w0 = c0; r.w1 = c1; r.w2 = c2; r.w3 = c3;
-}
-
-DEV Blk rng_block(const Rng& r, uint32_t blk, uint64_t seed) {
-    Blk b;
-    philox4x32_10(blk, r.sample, r.pixel, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), b);
-    return b;
-}
-// (float)(random_double() - 0.5f)   [sample_square, random.number.gen.hpp:16]:  (u - 2^31) * 2^-32, exact in double
-DEV float draw_centered(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 2.3283064365386963e-10f; }
-// (float)random_double(-1, 1)       [random.number.gen.hpp:12-14]:  -1 + 2u*2^-32 = (u - 2^31) * 2^-31, exact in double
-DEV float draw_pm1(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 4.6566128730773926e-10f; }
-
-// wave-wide vote straight from the compare (HIP's __ballot goes through an int and a second compare)
-DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-
-// The wave's draw service for the shading step.  Every draw is a pure function of (seed, pixel, sample, k), so any
-// lane can evaluate any Philox block of any other lane's stream; once per round each shading lane files one request
-// and the whole wave works them off, 64 blocks per pass:
-//   RQ_UNIT  random_unit_vector (random.number.gen.hpp:21-29; `> 1e-160` on a float is `> 0`).  A per-lane rejection
-//            loop costs the wave its longest run of rejections (6.6 passes for 1.9 attempts per lane at 52 %
-//            acceptance).  Every attempt takes one whole block (it starts at a block boundary and skips the fourth
-//            word), and each pass spreads the lanes still without a vector over all 64 lanes -- pass 1: one attempt
-//            each; pass 2: two attempts for each of the ~27 lanes left; pass 3: ~10 each.  Returns the vector.
-//   RQ_WORD  the raw draw at the current position (the dielectric's reflectance test, material.defs.cc:71): rides
-//            along in the first pass instead of costing the wave a Philox evaluation of its own at the occupancy of
-//            the dielectric branch.  Returns the bits in .x; the caller advances k if it consumes the draw.
-// `tbl` is 64 bytes of LDS private to the wave.
-enum : uint32_t { RQ_NONE = 0, RQ_UNIT = 1, RQ_WORD = 2 };
-
-// (an LDS-qualified pointer: through a generic one these accesses become flat_* instructions with full waits)
-typedef __attribute__((address_space(3))) uint8_t lds_u8;
-DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
-    V3 out = mk(0.0f, 0.0f, 0.0f);
-    if (code == RQ_UNIT) rng.k = (rng.k + 3u) & ~3u; // attempts are block aligned
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const uint32_t word_sel = code == RQ_WORD ? 4u + (rng.k & 3u) : 0u; // bit 2: a word request
-    bool pending = code != RQ_NONE;
-    uint64_t todo = ballot(pending);
-    while (todo != 0ull) {
-        const uint32_t n = (uint32_t)__popcll(todo);
-        const uint32_t per = min(64u / n, 8u); // attempts per pending lane in this pass
-        const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
-        if (pending) tbl[my_rank] = (uint8_t)lane; // rank -> lane of the pending stream
-        // this lane evaluates attempt `a` of the pending lane of rank `r`
-        const float inv_n = __builtin_amdgcn_rcpf((float)n);
-        const uint32_t a = (uint32_t)(((float)lane + 0.5f) * inv_n);
-        const uint32_t r = lane - a * n;
-        const bool helper = a < per;
-        const uint32_t src = tbl[r];
-        const uint32_t pix = (uint32_t)__shfl((int)rng.pixel, (int)src);
-        const uint32_t smp = (uint32_t)__shfl((int)(rng.sample | (word_sel << 16)), (int)src);
-        const uint32_t kb = (uint32_t)__shfl((int)rng.k, (int)src);
-        bool ok = false;
-        V3 u = mk(0.0f, 0.0f, 0.0f); // the accepted point, not yet normalised
-        if (helper) {
-            Blk tmp;
-            philox4x32_10((kb >> 2) + a, smp & 0xffffu, pix, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), tmp);
-            if (smp & 0x40000u) { // word request: word (k & 3) of block k >> 2
-                const uint32_t j = (smp >> 16) & 3u;
-                u.x = __uint_as_float(j == 0u ? tmp.w0 : (j == 1u ? tmp.w1 : (j == 2u ? tmp.w2 : tmp.w3)));
-                ok = a == 0u;
-            } else {
-                u = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
-                const float l2 = vdot(u, u);
-                ok = l2 > 0.0f && l2 <= 1.0f; // random.number.gen.hpp:25-27
-            }
-        }
-        const uint64_t okm = ballot(ok);
-        // the pending lane takes its first accepted attempt, in attempt order: its attempts sit at bits
-        // my_rank + c * n (c < per) of the vote
-        uint64_t stride_mask = 0ull;
-        for (uint32_t c = 0; c < per; ++c) stride_mask |= 1ull << (c * n); // wave-uniform
-        const uint64_t hits = (okm >> my_rank) & stride_mask;
-        const bool found = pending && hits != 0ull;
-        const uint32_t pos = (uint32_t)__builtin_ctzll(hits | (1ull << 63));
-        const uint32_t first = (uint32_t)(((float)pos + 0.5f) * inv_n);
-        const uint32_t from = found ? my_rank + pos : lane;
-        const float ux = __shfl(u.x, (int)from), uy = __shfl(u.y, (int)from), uz = __shfl(u.z, (int)from);
-        if (found) {
-            out = mk(ux, uy, uz);
-            if (code == RQ_UNIT) rng.k += 4u * (first + 1u);
-            pending = false;
-        } else if (pending) {
-            rng.k += 4u * per;
-        }
-        todo = ballot(pending);
-    }
-    // p / sqrt(dot(p, p)) once, on the owner's lane: the IEEE square root and divisions are not paid per attempt
-    if (code == RQ_UNIT) out = vdivs(out, __builtin_sqrtf(vdot(out, out)));
-    return out;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// lane state machine
-// ---------------------------------------------------------------------------------------------------------
-enum : uint32_t { PH_FETCH = 0, PH_GEN = 1, PH_TRAV = 2, PH_SHADE = 3, PH_DONE = 4, PH_BEGIN = 5 };
-constexpr uint32_t kNoWalk = 0xffffffffu; // RtmiLaunch::root_ref: every leaf is tested at segment set-up
-constexpr uint32_t kAttLds = 4; // closed attenuation runs kept in LDS per lane; more material changes spill to HBM
-
-struct Trav { // per-segment traversal state
-    V3 o, d;
-    float a;          // dot(d, d), object.defs.cc:44
-    float tbest;      // closest accepted root so far (Interval::Max, object.defs.cc:69)
-    uint32_t best;    // slot of the closest sphere, ~0u = none
-    uint32_t cur;     // BVH: current node/leaf reference; brute force: unused
-    uint32_t sp;      // BVH: LDS byte address of the next free entry of this lane's stack ([depth][lane] array)
-    V3 inv, oinv, pinv; // BVH slab test: 1/d, -o/d, pad*|1/d|
-};
-
-DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-// HittableObject_Sphere::intersects (object.defs.cc:41-60) in two halves.  The candidate root of a sphere does not
-// depend on the shrinking Max (root1 if it is beyond tmin, else root2); acceptance against Max is done by the caller.
-// Spheres are stored as {C, R*R}.
-// The discriminant (cheap, every sphere, every lane) and the root (IEEE sqrt and divisions, only where delta >= 0:
-// 0.4 % of the tests of the linear scan, which works on four spheres at a time).
-DEV void sphere_delta(const uint4 raw, const Trav& t, float& h, float& delta) {
-    const V3 oc = mk(__uint_as_float(raw.x) - t.o.x, __uint_as_float(raw.y) - t.o.y, __uint_as_float(raw.z) - t.o.z);
-    h = vdot(t.d, oc);
-    const float c = vdot(oc, oc) - __uint_as_float(raw.w);
-    delta = h * h - t.a * c;
-}
-DEV void sphere_root(float h, float delta, const Trav& t, uint32_t slot, float& tbest, uint32_t& best) {
-    const float sqrtd = __builtin_sqrtf(delta);
-    float root = (h - sqrtd) / t.a;
-    if (!(root > 0.0001f)) root = (h + sqrtd) / t.a;
-    if (root > 0.0001f && root < tbest) { // strict <: the first inserted object wins a tie (object.defs.cc:73)
-        tbest = root;
-        best = slot;
-    }
-}
-
-// Root + acceptance for the BVH walk, where leaves are not visited in insertion order: a strictly closer root wins; an
-// exactly equal one wins only if its object was inserted earlier (what the reference's in-order scan with `<` yields).
-DEV void sphere_root_bvh(float h, float delta, const Trav& t, uint32_t slot, const uint4* aux, float& tbest, uint32_t& best) {
-    const float sqrtd = __builtin_sqrtf(delta);
-    float root = (h - sqrtd) / t.a;
-    if (!(root > 0.0001f)) root = (h + sqrtd) / t.a;
-    if (root > 0.0001f) {
-        if (root < tbest) {
-            tbest = root;
-            best = slot;
-        } else if (root == tbest && best != ~0u) {
-            if (aux[slot].x < aux[best].x) best = slot;
-        }
-    }
-}
+#include "rtmi_kernel_common.h"
 
 // BIG = false: the whole scene is staged into LDS and stack entries are packed into 16 bits (<= 8192 spheres).
 // BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
@@ -1054,6 +770,12 @@ struct rtmi_scene {
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     uint32_t pre_leaf_dev[4] = {}; // leaves peeled off the top of the tree, tested at segment set-up
     uint32_t n_pre_leaves = 0;
+    // queue-scheduled kernel (rtmi_wavefront.hip): its own launch geometry and LDS carve-up behind the staged scene
+    bool wf_enabled = false;
+    uint32_t wf_block = 1024, wf_grid = 0, wf_lds_bytes = 0, wf_slots = 0, wf_cap = 0, wf_refill = 24;
+    uint32_t wf_lds_stack = 0, wf_lds_fields = 0, wf_lds_rings = 0, wf_lds_ctrl = 0;
+    int wf_wpe = 4;
+    uint32_t* d_wf_error = nullptr;
     hipStream_t stream = nullptr; // private stream of the blocking entry point
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -1093,6 +815,7 @@ void free_scene(rtmi_scene* s) {
     hipFree(s->d_rgba);
     hipFree(s->d_samples);
     hipFree(s->d_defer);
+    hipFree(s->d_wf_error);
     if (s->ev2) hipEventDestroy(s->ev2);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
@@ -1238,9 +961,26 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
 
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, 4 * sizeof(uint32_t), stream));
     if (first) HIP_TRY(hipEventRecord(s->ev0, stream));
-    KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big);
-    void* args[] = {&P};
-    HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
+    // queue-scheduled kernel: needs the sample records (any wave finishes any sample) and a tree to walk
+    const bool use_wf = s->wf_enabled && P.sample_buf != nullptr && s->accel == RTMI_ACCEL_BVH;
+    if (use_wf) {
+        P.defer_buf = nullptr;
+        P.lds_stack = s->wf_lds_stack;
+        P.wf_slots = s->wf_slots;
+        P.wf_cap_mask = s->wf_cap - 1u;
+        P.lds_wf_fields = s->wf_lds_fields;
+        P.lds_wf_rings = s->wf_lds_rings;
+        P.lds_wf_ctrl = s->wf_lds_ctrl;
+        P.wf_refill = s->wf_refill;
+        P.div_w = make_fastdiv(W);
+        P.wf_error = s->d_wf_error;
+        const int rc = rtmi_wavefront_launch(P, s->collect_stats, s->big, s->wf_wpe, s->wf_grid, s->wf_block, s->wf_lds_bytes, stream);
+        if (rc != RTMI_OK) return rc;
+    } else {
+        KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big);
+        void* args[] = {&P};
+        HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
+    }
     if (P.defer_buf) { // drain launch: same kernel, work items = the queued paths
         RtmiLaunch D = P;
         D.mode = 1;
@@ -1261,6 +1001,19 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         if (!first) HIP_TRY(hipEventRecord(s->ev2, stream)); // banded call: trace and resolve launches interleave
         HIP_TRY(hipEventRecord(s->ev1, stream));
         s->ev_valid = true;
+    }
+    return RTMI_OK;
+}
+
+// the queue-scheduled kernel bounds every wait; a watchdog that fired means the frame is incomplete
+int check_watchdog(rtmi_scene* s) {
+    if (!s->d_wf_error) return RTMI_OK;
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, s->d_wf_error, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag != 0u) {
+        (void)hipMemset(s->d_wf_error, 0, sizeof(flag));
+        set_error("rtmi: the queue-scheduled kernel aborted on its watchdog (a ring wait did not end); frame incomplete");
+        return RTMI_ERR_HIP;
     }
     return RTMI_OK;
 }
@@ -1516,10 +1269,56 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     s->top_down = tune.top_down != 0;
     s->grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
 
+    // ---- queue-scheduled kernel: slot pool, rings and control words behind the staged scene and the stacks ------------
+    s->wf_enabled = s->accel == RTMI_ACCEL_BVH && n_objects > 0 && tune.kernel == 2u; // 0 / 1: round-based kernel
+    if (s->wf_enabled) {
+        if (tune.wf_block_lanes) s->wf_block = std::min(1024u, std::max(64u, (tune.wf_block_lanes / 64u) * 64u));
+        if (tune.wf_refill) s->wf_refill = std::min(64u, tune.wf_refill);
+        const uint32_t per_cu_target = s->wf_block <= 768u ? 2u : 1u;
+        s->wf_wpe = s->wf_block <= 768u ? 6 : 4;
+        const uint32_t limit = (160u * 1024u) / per_cu_target;
+        uint32_t base = 0;
+        if (!s->big) base = align16((uint32_t)s->bvh.nodes.size() * 64u + n_objects * 32u + n_materials * 16u);
+        s->wf_lds_stack = base;
+        base = align16(base + s->stack_depth * s->wf_block * (s->big ? 4u : 2u));
+        const uint32_t ctrl_bytes = (16u + (s->wf_block / 64u) * 20u) * 4u;
+        uint32_t ns = tune.wf_slots ? std::min(0xfffeu & ~63u, std::max(64u, (tune.wf_slots / 64u) * 64u)) : 2u * s->wf_block;
+        for (;; ns -= 64u) {
+            uint32_t cap = 64u;
+            while (cap < ns) cap <<= 1;
+            const uint64_t total = (uint64_t)base + (uint64_t)ns * kWfFields * 4u + 4ull * cap * 2u + ctrl_bytes;
+            if (total <= limit || ns <= 64u) {
+                s->wf_slots = ns;
+                s->wf_cap = cap;
+                s->wf_lds_fields = base;
+                s->wf_lds_rings = align16(base + ns * kWfFields * 4u);
+                s->wf_lds_ctrl = align16(s->wf_lds_rings + 4u * cap * 2u);
+                s->wf_lds_bytes = align16(s->wf_lds_ctrl + ctrl_bytes);
+                break;
+            }
+        }
+        if (s->wf_lds_bytes > 160u * 1024u) {
+            set_error("rtmi_scene_create: the queue-scheduled kernel does not fit the 160 KiB LDS of a CU with this scene");
+            return fail(RTMI_ERR_UNSUPPORTED);
+        }
+        int wf_per_cu = 0;
+        const int rc = rtmi_wavefront_occupancy(s->collect_stats, s->big, s->wf_wpe, s->wf_block, s->wf_lds_bytes, &wf_per_cu);
+        if (rc != RTMI_OK) return fail(rc);
+        if (wf_per_cu < 1) {
+            set_error("rtmi_scene_create: the queue-scheduled kernel cannot be resident with this scene");
+            return fail(RTMI_ERR_UNSUPPORTED);
+        }
+        if (tune.blocks_per_cu) wf_per_cu = std::max(1, std::min(wf_per_cu, (int)tune.blocks_per_cu));
+        s->wf_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)wf_per_cu;
+        HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_wf_error), 16));
+        HIP_TRY_S(hipMemset(s->d_wf_error, 0, 16));
+    }
+
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_counter), 16));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 64 * sizeof(unsigned long long)));
     HIP_TRY_S(hipMemset(s->d_stats, 0, 64 * sizeof(unsigned long long)));
-    const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * s->grid * s->block * 2u * sizeof(uint32_t));
+    const size_t att_lanes = std::max<size_t>((size_t)s->grid * s->block, (size_t)s->wf_grid * s->wf_slots);
+    const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * att_lanes * 2u * sizeof(uint32_t));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_att), att_bytes));
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY_S(hipEventCreate(&s->ev0));
@@ -1605,7 +1404,7 @@ static int render_rows_impl(rtmi_scene* s, uint32_t y0, uint32_t y1, uint64_t se
         HIP_TRY(hipMemcpyAsync(rgba8_out, s->d_rgba, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return RTMI_OK;
+    return check_watchdog(s);
 }
 
 extern "C" int rtmi_render_rows(rtmi_scene* s, uint32_t y0, uint32_t y1, uint64_t seed, float* rgb_linear_out,
@@ -1678,7 +1477,7 @@ extern "C" int rtmi_scene_last_kernel_ms(rtmi_scene* s, float* ms_out) {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventSynchronize(s->ev1));
     HIP_TRY(hipEventElapsedTime(ms_out, s->ev0, s->ev2)); // the trace kernel alone; the resolve pass follows it
-    return RTMI_OK;
+    return check_watchdog(s);
 }
 
 #ifdef RTMI_PROF
