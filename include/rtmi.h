@@ -198,7 +198,7 @@ const char* rtmi_version(void);
 int rtmi_scene_get_stats(rtmi_scene* scene, rtmi_stats* out, int reset);
 /* which kernel rtmi_render_* will launch for this scene: RTMI_ACCEL_BRUTE or RTMI_ACCEL_BVH */
 int rtmi_scene_get_accel(const rtmi_scene* scene, uint32_t* accel_out);
-/* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), 0}. */
+/* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), rmax^2}. */
 int rtmi_scene_get_bvh(const rtmi_scene* scene, rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out,
                        uint32_t* n_slots, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,
                        float* pad_floor);

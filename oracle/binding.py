@@ -79,6 +79,10 @@ def lib():
     L.orc_counter_double.restype = C.c_double
     L.orc_counter_double.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     L.orc_philox4x32_10.argtypes = [vp, vp, vp]
+    L.orc_philox4x32.argtypes = [C.c_int, vp, vp, vp]
+    L.orc_pcg4d.argtypes = [vp, vp]
+    L.orc_set_counter_rng.argtypes = [C.c_int]
+    L.orc_get_counter_rng.restype = C.c_int
     L.orc_camera_setup.argtypes = [C.POINTER(CameraParams), C.POINTER(Camera)]
     L.orc_make_world_spheres.restype = C.c_uint32
     L.orc_make_world_spheres.argtypes = [C.POINTER(WorldDef), vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp,
@@ -107,6 +111,15 @@ def lib():
                                C.POINTER(C.c_uint64)]
     _lib = L
     return L
+
+
+def set_counter_rng(kind):
+    """Block function of the counter stream: 10 / 7 = Philox4x32 rounds, 0 = pcg4d (must match the product's RTMI_RNG)."""
+    lib().orc_set_counter_rng(int(kind))
+
+
+def get_counter_rng():
+    return int(lib().orc_get_counter_rng())
 
 
 def _ptr(a):

@@ -101,11 +101,11 @@ static uint32_t mt_next(orc_rng* r) {
     return y;
 }
 
-/* Philox4x32-10 (Salmon et al., SC'11), the per-lane counter RNG of the GPU path. */
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+/* Philox4x32-R (Salmon et al., SC'11), the per-lane counter RNG of the GPU path. */
+void orc_philox4x32(int rounds, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < rounds; ++round) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -117,6 +117,37 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
         k1 += 0xBB67AE85u;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32(10, ctr, key, out); }
+
+/* pcg4d (Jarzynski & Olano, "Hash Functions for GPU Rendering", JCGT 9(3), 2020, listing of the 4-d PCG hash) with one more
+ * xorshift on the way out: without it the low three bits of a word are biased (tests/test_oracle_cpu.py) */
+void orc_pcg4d(const uint32_t in[4], uint32_t out[4]) {
+    uint32_t x = in[0], y = in[1], z = in[2], w = in[3];
+    x = x * 1664525u + 1013904223u;
+    y = y * 1664525u + 1013904223u;
+    z = z * 1664525u + 1013904223u;
+    w = w * 1664525u + 1013904223u;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    out[0] = x; out[1] = y; out[2] = z; out[3] = w;
+}
+
+/* Block function of the counter stream -- the same build-time choice the product makes with RTMI_RNG
+ * (raytracing.cpp_amd/csrc/rtmi_kernel_common.h): 10 or 7 = Philox4x32 rounds, 0 = pcg4d. */
+static int g_counter_rng = ORC_COUNTER_RNG_DEFAULT;
+void orc_set_counter_rng(int kind) { g_counter_rng = kind; }
+int orc_get_counter_rng(void) { return g_counter_rng; }
+void orc_counter_block(uint32_t blk, uint32_t sample, uint32_t pixel, const uint32_t key[2], uint32_t out[4]) {
+    if (g_counter_rng == 0) {
+        const uint32_t in[4] = {blk, sample ^ key[1], pixel, key[0]};
+        orc_pcg4d(in, out);
+    } else {
+        const uint32_t ctr[4] = {blk, sample, pixel, 0u};
+        orc_philox4x32(g_counter_rng, ctr, key, out);
+    }
 }
 
 /* libstdc++ std::generate_canonical<double,53>(urng32) as used by
@@ -147,12 +178,11 @@ static inline double rd(orc_rng* r) {
         return canonical_from_u32_pair(lo, hi);
     }
     /* counter stream (BUILD-SIDE replacement of `_randdist(_randgen)`): draw #k of (seed, pixel, sample) is
-     * word (k & 3) of Philox4x32-10(ctr = {k >> 2, sample, pixel, 0}, key = seed), mapped to [0,1) as
+     * word (k & 3) of block k >> 2 of that stream (orc_counter_block: pcg4d, or Philox4x32 in the A/B), mapped to [0,1) as
      * u32 * 2^-32 (exact in double).  Everything downstream of random_double() is unchanged. */
     const uint32_t k = r->k++;
     if ((k & 3u) == 0u) {
-        const uint32_t ctr[4] = {k >> 2, r->sample, r->pixel, 0u};
-        orc_philox4x32_10(ctr, r->key, r->cache);
+        orc_counter_block(k >> 2, r->sample, r->pixel, r->key, r->cache);
     }
     return (double)r->cache[k & 3u] * (1.0 / 4294967296.0);
 }
@@ -172,7 +202,7 @@ static inline v3 random_vector_range(orc_rng* r, double rmin, double rmax) {
  * against a double below the smallest float denormal, i.e. `> 0`. */
 static inline v3 random_unit_vector(orc_rng* r) {
     for (;;) {
-        /* counter stream only (build-side): every attempt takes one whole Philox block -- it starts at a block
+        /* counter stream only (build-side): every attempt takes one whole block -- it starts at a block
          * boundary and skips the fourth word -- so that any GPU lane can evaluate any attempt of any stream */
         if (r->kind == ORC_RNG_COUNTER) r->k = (r->k + 3u) & ~3u;
         const v3 p = random_vector_range(r, -1.0, 1.0);
@@ -492,7 +522,7 @@ static inline float ray_pad(const scene_t* sc, const ray_t* r) {
             const float m = fmaxf(d0 * d0, d1 * d1);
             far2 = far2 + m;
         }
-        const float x = sc->pad_eps * far2; /* sqrt(R^2 + x) - R <= min(x / (2R), sqrt(x)) */
+        const float x = sc->pad_eps * (far2 + k[7]); /* k[7] = rmax^2 of the class; sqrt(R^2 + x) - R <= min(x / (2R), sqrt(x)) */
         const float ec = fminf(x * k[6], sqrtf(x) * 1.000001f);
         e = fmaxf(e, ec);
     }

@@ -109,6 +109,15 @@ uint32_t orc_mt_next_u32(orc_rng*);
 /* k-th double of the counter stream of (seed, pixel, sample) */
 double orc_counter_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_philox4x32(int rounds, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_pcg4d(const uint32_t in[4], uint32_t out[4]);
+/* block function of the counter stream: 10 / 7 = Philox4x32 rounds, 0 = pcg4d (the product's RTMI_RNG) */
+#ifndef ORC_COUNTER_RNG_DEFAULT
+#define ORC_COUNTER_RNG_DEFAULT 0
+#endif
+void orc_set_counter_rng(int kind);
+int orc_get_counter_rng(void);
+void orc_counter_block(uint32_t blk, uint32_t sample, uint32_t pixel, const uint32_t key[2], uint32_t out[4]);
 
 /* --- host-side setup ------------------------------------------------------ */
 void orc_camera_setup(const orc_camera_params* p, orc_camera* out);

@@ -23,7 +23,7 @@
 //    second launch (DRAIN variant) whose lanes all walk such paths -- for launches long enough to pay for it.
 //  * scene (BVH nodes, spheres, materials) staged once per workgroup into LDS with coalesced 16-byte loads; the
 //    per-lane traversal stack lives in LDS too.  Scenes that do not fit stay in HBM (BIG variant) behind L2 / Infinity Cache.
-//  * counter RNG: Philox4x32-10 keyed by seed, counter (draw block, sample, pixel): the image does not depend on
+//  * counter RNG: a block function (pcg4d; Philox4x32 in the A/B) of (seed, draw block, sample, pixel): the image does not depend on
 //    tiling, row sharding or GPU count.
 //  * arithmetic of the reference path is kept operation for operation (no FMA contraction, IEEE sqrt/div); only the
 //    BVH slab tests, which the reference does not have, use FMA.
@@ -183,7 +183,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                 const float az = fmaxf((o.z - k[2]) * (o.z - k[2]), (k[5] - o.z) * (k[5] - o.z));
                 // sqrt(R^2 + x) - R <= min(x / (2R), sqrt(x)): the linear bound explodes for a ray that starts thousands of
                 // units away (a path inside the ground sphere), the square root does not
-                const float x = P.pad_eps * ((ax + ay) + az);
+                const float x = P.pad_eps * (((ax + ay) + az) + k[7]); // k[7]: rmax^2 of the class
                 pad = fmaxf(pad, fminf(x * k[6], __builtin_amdgcn_sqrtf(x) * 1.000001f));
             }
             t.oinv = mk(-(o.x * t.inv.x), -(o.y * t.inv.y), -(o.z * t.inv.z));
@@ -1281,7 +1281,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         if (!s->big) base = align16((uint32_t)s->bvh.nodes.size() * 64u + n_objects * 32u + n_materials * 16u);
         s->wf_lds_stack = base;
         base = align16(base + s->stack_depth * s->wf_block * (s->big ? 4u : 2u));
-        const uint32_t ctrl_bytes = (16u + (s->wf_block / 64u) * 20u) * 4u;
+        const uint32_t ctrl_bytes = (16u + (s->wf_block / 64u) * 16u) * 4u; // control words + a 64-byte rank table per wave
         uint32_t ns = tune.wf_slots ? std::min(0xfffeu & ~63u, std::max(64u, (tune.wf_slots / 64u) * 64u)) : 2u * s->wf_block;
         for (;; ns -= 64u) {
             uint32_t cap = 64u;

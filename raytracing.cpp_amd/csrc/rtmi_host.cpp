@@ -466,12 +466,17 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
         out.root_ref = 0;
     }
 
-    // Per-ray pad: a sphere of radius R seen from distance L is accepted by the fp32 discriminant of
-    // object.defs.cc:43-50 only if the ray passes within sqrt(R^2 + k*u*L^2) of its centre (u = 2^-24, k <= 15),
-    // i.e. within R + k*u*L^2/(2R).  Spheres are grouped into radius classes; the kernel evaluates
-    // pad = max_c(pad_eps * far2(origin, centre_box_c) / (2 rmin_c)) once per ray segment.
-    out.pad_eps = 32.0f * 5.9604645e-8f;
-    out.pad_floor = std::max(8.0f * 5.9604645e-8f * maxabs, 1e-6f);
+    // Per-ray pad (derivation: DESIGN.md, "Exactness of the BVH").  With u = 2^-24, L = |C - O| and M = max(L, R), the
+    // fp32 arithmetic of object.defs.cc:43-60 accepts a sphere only if the ray's line passes within sqrt(R^2 + 25 u M^2) of
+    // the centre, and the point of every root it accepts lies within sqrt(R^2 + 50 u M^2) of it.  The walk must reach the
+    // sphere whenever that point is inside the search interval, i.e. the point must lie inside the sphere's (and every
+    // ancestor's) box: boxes are padded per ray segment by
+    //     max_c min(x_c / (2 rmin_c), sqrt(x_c)),   x_c = pad_eps * (far^2(origin, centres of class c) + rmax_c^2),
+    // over radius classes c (sqrt(R^2 + x) - R <= min(x / 2R, sqrt(x))), with pad_eps = 64 u >= 50 u plus the
+    // second-order terms, and never by less than pad_floor = 16 u * (largest box coordinate), which covers the rounding
+    // of the slab test itself (v_rcp_f32 and two FMAs per plane on coordinates of that size).
+    out.pad_eps = 64.0f * 5.9604645e-8f;
+    out.pad_floor = std::max(16.0f * 5.9604645e-8f * maxabs, 1e-6f);
     out.n_pad_classes = 0;
     if (n) {
         const float l0 = std::log2(std::max(rmin_all, 1e-30f));
@@ -479,6 +484,7 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
         const float step = (l1 - l0) / static_cast<float>(kMaxPadClasses);
         Box cb[kMaxPadClasses];
         float rmin[kMaxPadClasses];
+        float rmax[kMaxPadClasses] = {};
         bool used[kMaxPadClasses] = {};
         for (uint32_t k = 0; k < kMaxPadClasses; ++k) {
             cb[k].reset();
@@ -493,6 +499,7 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
             }
             used[k] = true;
             rmin[k] = std::min(rmin[k], r);
+            rmax[k] = std::max(rmax[k], r);
             for (int a = 0; a < 3; ++a) {
                 cb[k].lo[a] = std::min(cb[k].lo[a], objects[i].center[a]);
                 cb[k].hi[a] = std::max(cb[k].hi[a], objects[i].center[a]);
@@ -506,7 +513,7 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
                 pc[3 + a] = cb[k].hi[a];
             }
             pc[6] = 1.0f / (2.0f * rmin[k]);
-            pc[7] = 0.0f;
+            pc[7] = up(rmax[k] * rmax[k]);
         }
     }
 }

@@ -136,7 +136,7 @@ DEV V3 vrefract(V3 I, V3 N, float eta) {
 DEV V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------------------------------------------------
-// counter RNG: draw #k of (seed, pixel, sample) = word (k & 3) of Philox4x32-10({k >> 2, sample, pixel, 0}, seed);
+// counter RNG: draw #k of (seed, pixel, sample) = word (k & 3) of block k >> 2 of that stream (rng4x32 below);
 // random_double() = u32 * 2^-32.  The affine maps of random.number.gen.hpp are exact in double for a 32-bit
 // draw, so the double -> float narrowing of the reference equals one int -> float conversion here.
 // ---------------------------------------------------------------------------------------------------------
@@ -147,9 +147,22 @@ struct Blk {
     uint32_t w0, w1, w2, w3;
 };
 
-DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, Blk& r) {
+// The block function of the counter RNG: 128 bits from (block, sample, pixel | seed).  RTMI_RNG picks it at build time
+// (the oracle has the same switch at run time, oracle/rt_oracle.c):
+//   10, 7   Philox4x32 with that many rounds (Salmon et al., SC'11; 7 rounds are the fewest that pass BigCrush there,
+//           10 the library default with its safety margin)
+//   0       pcg4d (Jarzynski & Olano, "Hash Functions for GPU Rendering", JCGT 9(3), 2020): 12 multiplies, plus one
+//           more xorshift on the way out (without it the low three bits of a word are biased: 25 / 37 / 44 % ones over
+//           the pixels of a frame, measured; with it every bit is within 0.1 % of one half)
+// Issue cost on MI355X (tools/ubench: v_mul_lo / v_mul_hi 1.7x a v_fma_f32): ~280 / ~196 / ~130 cycles per block;
+// whole 1080p x 512 spp frame, same build otherwise: 186.8 / 178.6 / 172.1 ms (tools/rng_ab.py).  Shipped: 0.
+#ifndef RTMI_RNG
+#define RTMI_RNG 0
+#endif
+template <int ROUNDS>
+DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, Blk& r) {
 #pragma unroll
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < ROUNDS; ++round) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -162,10 +175,29 @@ DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     }
     r.w0 = c0; r.w1 = c1; r.w2 = c2; r.w3 = c3;
 }
+DEV void pcg4d(uint32_t x, uint32_t y, uint32_t z, uint32_t w, Blk& r) {
+    x = x * 1664525u + 1013904223u;
+    y = y * 1664525u + 1013904223u;
+    z = z * 1664525u + 1013904223u;
+    w = w * 1664525u + 1013904223u;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    r.w0 = x; r.w1 = y; r.w2 = z; r.w3 = w;
+}
+// block `blk` of the stream (seed, pixel, sample)
+DEV void rng4x32(uint32_t blk, uint32_t sample, uint32_t pixel, uint64_t seed, Blk& r) {
+#if RTMI_RNG == 0
+    pcg4d(blk, sample ^ (uint32_t)(seed >> 32), pixel, (uint32_t)seed, r);
+#else
+    philox4x32<RTMI_RNG>(blk, sample, pixel, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#endif
+}
 
 DEV Blk rng_block(const Rng& r, uint32_t blk, uint64_t seed) {
     Blk b;
-    philox4x32_10(blk, r.sample, r.pixel, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), b);
+    rng4x32(blk, r.sample, r.pixel, seed, b);
     return b;
 }
 // (float)(random_double() - 0.5f)   [sample_square, random.number.gen.hpp:16]:  (u - 2^31) * 2^-32, exact in double
@@ -177,7 +209,7 @@ DEV float draw_pm1(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 4.65
 DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // The wave's draw service for the shading step.  Every draw is a pure function of (seed, pixel, sample, k), so any
-// lane can evaluate any Philox block of any other lane's stream; once per round each shading lane files one request
+// lane can evaluate any block of any other lane's stream; once per round each shading lane files one request
 // and the whole wave works them off, 64 blocks per pass:
 //   RQ_UNIT  random_unit_vector (random.number.gen.hpp:21-29; `> 1e-160` on a float is `> 0`).  A per-lane rejection
 //            loop costs the wave its longest run of rejections (6.6 passes for 1.9 attempts per lane at 52 %
@@ -185,7 +217,7 @@ DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 //            word), and each pass spreads the lanes still without a vector over all 64 lanes -- pass 1: one attempt
 //            each; pass 2: two attempts for each of the ~27 lanes left; pass 3: ~10 each.  Returns the vector.
 //   RQ_WORD  the raw draw at the current position (the dielectric's reflectance test, material.defs.cc:71): rides
-//            along in the first pass instead of costing the wave a Philox evaluation of its own at the occupancy of
+//            along in the first pass instead of costing the wave a block evaluation of its own at the occupancy of
 //            the dielectric branch.  Returns the bits in .x; the caller advances k if it consumes the draw.
 // `tbl` is 64 bytes of LDS private to the wave.
 enum : uint32_t { RQ_NONE = 0, RQ_UNIT = 1, RQ_WORD = 2 };
@@ -217,7 +249,7 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
         V3 u = mk(0.0f, 0.0f, 0.0f); // the accepted point, not yet normalised
         if (helper) {
             Blk tmp;
-            philox4x32_10((kb >> 2) + a, smp & 0xffffu, pix, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), tmp);
+            rng4x32((kb >> 2) + a, smp & 0xffffu, pix, seed, tmp);
             if (smp & 0x40000u) { // word request: word (k & 3) of block k >> 2
                 const uint32_t j = (smp >> 16) & 3u;
                 u.x = __uint_as_float(j == 0u ? tmp.w0 : (j == 1u ? tmp.w1 : (j == 2u ? tmp.w2 : tmp.w3)));

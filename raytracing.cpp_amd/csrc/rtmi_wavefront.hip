@@ -54,13 +54,52 @@ enum : uint32_t { C_LIVE = 8, C_ABORT = 9, C_POOLS = 16 }; // control words; [2q
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr uint32_t kAttSlot = 2; // closed attenuation runs kept in the slot (LDS-resident scenes)
 
+// LDS-qualified pointer types: through generic pointers the volatile ring accesses become flat_* instructions with
+// system-scope cache bits and full waits (the address-space inference pass leaves volatile accesses alone)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+typedef __attribute__((address_space(3))) volatile uint16_t lds_vu16;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+DEV uint32_t lds_fetch_add(lds_u32* p, uint32_t v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+DEV uint32_t lds_fetch_sub(lds_u32* p, uint32_t v) {
+    return __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+DEV bool lds_cas(lds_u32* p, uint32_t expected, uint32_t desired) {
+    return __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <bool BIG>
 struct Scene { // where the kernel reads the scene from: LDS copies, or HBM behind L1 / L2 / Infinity Cache
-    const uint4* spheres;
-    const uint4* aux;
-    const uint4* mats;
-    const uint4* nodes;
+    using Ptr = typename std::conditional<BIG, const u32x4*, lds_cu32x4*>::type;
+    Ptr spheres, aux, mats, nodes;
+    static __device__ __forceinline__ uint4 ld(Ptr p, uint32_t i) {
+        const u32x4 v = p[i];
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
 };
+
+// sphere_root_bvh of rtmi_kernel_common.h with the scene's pointer type for the tie rule's look-up
+template <bool BIG>
+DEV void sphere_root_tie(float h, float delta, const Trav& t, uint32_t slot, typename Scene<BIG>::Ptr aux, float& tbest,
+                         uint32_t& best) {
+    const float sqrtd = __builtin_sqrtf(delta);
+    float root = (h - sqrtd) / t.a;
+    if (!(root > 0.0001f)) root = (h + sqrtd) / t.a;
+    if (root > 0.0001f) {
+        if (root < tbest) {
+            tbest = root;
+            best = slot;
+        } else if (root == tbest && best != ~0u) {
+            if (aux[slot].x < aux[best].x) best = slot;
+        }
+    }
+}
 
 // the spheres of one leaf against the segment in `t` (same routine as the round-based kernel)
 template <bool BIG, bool STATS>
@@ -69,13 +108,13 @@ DEV void test_leaf(const Scene<BIG>& sc, Trav& t, uint32_t ref, uint32_t& st_sph
     const uint32_t cnt = BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u);
     auto pair = [&](uint32_t q) {
         const bool two = q + 1u < cnt;
-        const uint4 r0 = sc.spheres[first + q];
-        const uint4 r1 = sc.spheres[first + q + (two ? 1u : 0u)];
+        const uint4 r0 = Scene<BIG>::ld(sc.spheres, first + q);
+        const uint4 r1 = Scene<BIG>::ld(sc.spheres, first + q + (two ? 1u : 0u));
         float h0, h1, d0, d1;
         sphere_delta(r0, t, h0, d0);
         sphere_delta(r1, t, h1, d1);
-        if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, first + q, sc.aux, t.tbest, t.best);
-        if (two & (d1 >= 0.0f)) sphere_root_bvh(h1, d1, t, first + q + 1u, sc.aux, t.tbest, t.best);
+        if (d0 >= 0.0f) sphere_root_tie<BIG>(h0, d0, t, first + q, sc.aux, t.tbest, t.best);
+        if (two & (d1 >= 0.0f)) sphere_root_tie<BIG>(h1, d1, t, first + q + 1u, sc.aux, t.tbest, t.best);
     };
     pair(0u);
     if (cnt > 2u) {
@@ -93,44 +132,44 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t NS = P.wf_slots, mask = P.wf_cap_mask, cap = mask + 1u;
     const uint32_t W = P.cam.img_width, spp = P.cam.samples_per_pixel, maxdepth = P.cam.maxdepth;
-    uint32_t* const fields = reinterpret_cast<uint32_t*>(lds_raw + P.lds_wf_fields);
-    volatile uint16_t* const cells = reinterpret_cast<volatile uint16_t*>(lds_raw + P.lds_wf_rings);
-    volatile uint32_t* const ctrl = reinterpret_cast<volatile uint32_t*>(lds_raw + P.lds_wf_ctrl);
-    uint32_t* const ctrl_rw = reinterpret_cast<uint32_t*>(lds_raw + P.lds_wf_ctrl);
-    uint32_t* const pool = ctrl_rw + C_POOLS + wave * 20u; // {work_next, work_end, -, -, 64-byte rank table of coop_draws}
-    lds_u8* const rank_tbl = (lds_u8*)(pool + 4);
+    lds_u32* const fields = (lds_u32*)(lds_raw + P.lds_wf_fields);
+    lds_vu16* const cells = (lds_vu16*)(lds_raw + P.lds_wf_rings);
+    lds_vu32* const ctrl = (lds_vu32*)(lds_raw + P.lds_wf_ctrl);
+    lds_u32* const ctrl_rw = (lds_u32*)(lds_raw + P.lds_wf_ctrl);
+    lds_u8* const rank_tbl = (lds_u8*)(ctrl_rw + C_POOLS + wave * 16u); // 64 bytes per wave, see coop_draws
     const uint32_t sp0 = P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT), sp_stride = blockDim.x * (uint32_t)sizeof(StackT);
     const uint32_t sp1 = sp0 + sp_stride;
-    *reinterpret_cast<StackT*>(lds_raw + sp0) = (StackT)kStackEnd; // entry 0: the sentinel that ends a walk
+    typedef __attribute__((address_space(3))) StackT lds_stack_t;
+    *(lds_stack_t*)(lds_raw + sp0) = (StackT)kStackEnd; // entry 0: the sentinel that ends a walk
 
     // ---- set-up: rings empty, scene staged, every slot FRESH in Q_E -------------------------------------------------
     for (uint32_t i = threadIdx.x; i < kNumQ * cap; i += blockDim.x) cells[i] = (uint16_t)kCellEmpty;
     if (threadIdx.x < C_POOLS) ctrl[threadIdx.x] = 0u;
-    if (lane == 0u) {
-        pool[0] = 0u;
-        pool[1] = 0u;
-    }
     Scene<BIG> sc;
     if (BIG) {
-        sc.spheres = P.spheres;
-        sc.aux = P.aux;
-        sc.mats = P.mats;
-        sc.nodes = P.nodes;
+        sc.spheres = (typename Scene<BIG>::Ptr)(const u32x4*)P.spheres;
+        sc.aux = (typename Scene<BIG>::Ptr)(const u32x4*)P.aux;
+        sc.mats = (typename Scene<BIG>::Ptr)(const u32x4*)P.mats;
+        sc.nodes = (typename Scene<BIG>::Ptr)(const u32x4*)P.nodes;
     } else {
-        uint4* w_spheres = reinterpret_cast<uint4*>(lds_raw + P.lds_spheres);
-        uint4* w_aux = reinterpret_cast<uint4*>(lds_raw + P.lds_aux);
-        uint4* w_mats = reinterpret_cast<uint4*>(lds_raw + P.lds_mats);
-        uint4* w_nodes = reinterpret_cast<uint4*>(lds_raw);
+        lds_u32x4* w_spheres = (lds_u32x4*)(lds_raw + P.lds_spheres);
+        lds_u32x4* w_aux = (lds_u32x4*)(lds_raw + P.lds_aux);
+        lds_u32x4* w_mats = (lds_u32x4*)(lds_raw + P.lds_mats);
+        lds_u32x4* w_nodes = (lds_u32x4*)(lds_raw);
+        const u32x4* g_spheres = (const u32x4*)P.spheres;
+        const u32x4* g_aux = (const u32x4*)P.aux;
+        const u32x4* g_mats = (const u32x4*)P.mats;
+        const u32x4* g_nodes = (const u32x4*)P.nodes;
         for (uint32_t i = threadIdx.x; i < P.n_slots; i += blockDim.x) {
-            w_spheres[i] = P.spheres[i];
-            w_aux[i] = P.aux[i];
+            w_spheres[i] = g_spheres[i];
+            w_aux[i] = g_aux[i];
         }
-        for (uint32_t i = threadIdx.x; i < P.n_mats; i += blockDim.x) w_mats[i] = P.mats[i];
-        for (uint32_t i = threadIdx.x; i < 4u * P.n_nodes; i += blockDim.x) w_nodes[i] = P.nodes[i];
-        sc.spheres = w_spheres;
-        sc.aux = w_aux;
-        sc.mats = w_mats;
-        sc.nodes = w_nodes;
+        for (uint32_t i = threadIdx.x; i < P.n_mats; i += blockDim.x) w_mats[i] = g_mats[i];
+        for (uint32_t i = threadIdx.x; i < 4u * P.n_nodes; i += blockDim.x) w_nodes[i] = g_nodes[i];
+        sc.spheres = (typename Scene<BIG>::Ptr)w_spheres;
+        sc.aux = (typename Scene<BIG>::Ptr)w_aux;
+        sc.mats = (typename Scene<BIG>::Ptr)w_mats;
+        sc.nodes = (typename Scene<BIG>::Ptr)w_nodes;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < NS; i += blockDim.x) {
@@ -145,9 +184,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
     __syncthreads();
 
     uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0;
+    PF_DECL
     const size_t gslot0 = (size_t)blockIdx.x * NS; // first slot of this workgroup in the HBM strip of attenuation runs
 
-    auto fld = [&](uint32_t f, uint32_t slot) -> uint32_t& { return fields[f * NS + slot]; };
+    auto fld = [&](uint32_t f, uint32_t slot) -> lds_u32& { return fields[f * NS + slot]; };
     auto raise_abort = [&]() { ctrl[C_ABORT] = 1u; };
 
     // ---- rings ---------------------------------------------------------------------------------------------------
@@ -158,10 +198,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         const uint32_t n = (uint32_t)__popcll(m);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         uint32_t base = 0u;
-        if (pred && rank == 0u) base = atomicAdd(&ctrl_rw[2u * q + 1u], n);
+        if (pred && rank == 0u) base = lds_fetch_add(&ctrl_rw[2u * q + 1u], n);
         base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
         if (pred) {
-            volatile uint16_t* cell = cells + q * cap + ((base + rank) & mask);
+            lds_vu16* cell = cells + q * cap + ((base + rank) & mask);
             uint32_t guard = 0u;
             while (*cell != (uint16_t)kCellEmpty) { // the reader of the previous lap has not emptied it yet
                 __builtin_amdgcn_s_sleep(1);
@@ -177,7 +217,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
     auto pop = [&](uint32_t q, uint32_t want, uint32_t& slot) -> uint32_t {
         uint32_t h = 0u, n = 0u;
         if (lane == 0u) {
-            for (int tries = 0; tries < 16; ++tries) {
+#pragma unroll 1
+            for (int tries = 0; tries < 8; ++tries) {
                 h = ctrl[2u * q];
                 const uint32_t t = ctrl[2u * q + 1u];
                 n = min(t - h, want);
@@ -185,7 +226,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                     n = 0u;
                     break;
                 }
-                if (atomicCAS(&ctrl_rw[2u * q], h, h + n) == h) break;
+                if (lds_cas(&ctrl_rw[2u * q], h, h + n)) break;
                 n = 0u;
             }
         }
@@ -193,7 +234,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
         slot = 0u;
         if (lane < n) {
-            volatile uint16_t* cell = cells + q * cap + ((h + lane) & mask);
+            lds_vu16* cell = cells + q * cap + ((h + lane) & mask);
             uint32_t guard = 0u;
             uint32_t v = *cell;
             while (v == kCellEmpty) { // the writer has reserved the position and is about to fill it
@@ -267,7 +308,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         }
     };
     auto att_apply = [&](V3 color, uint32_t h, uint32_t n) -> V3 {
-        const uint4 m0 = sc.mats[h];
+        const uint4 m0 = Scene<BIG>::ld(sc.mats, h);
         const V3 a = mk(__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z));
         for (uint32_t c = 0; c < n; ++c) color = vmul(a, color); // A*(A*(...)): one multiply per bounce, in order
         return color;
@@ -288,7 +329,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                 const float ax = fmaxf((o.x - k[0]) * (o.x - k[0]), (k[3] - o.x) * (k[3] - o.x));
                 const float ay = fmaxf((o.y - k[1]) * (o.y - k[1]), (k[4] - o.y) * (k[4] - o.y));
                 const float az = fmaxf((o.z - k[2]) * (o.z - k[2]), (k[5] - o.z) * (k[5] - o.z));
-                const float x = P.pad_eps * ((ax + ay) + az);
+                const float x = P.pad_eps * (((ax + ay) + az) + k[7]); // k[7]: rmax^2 of the class
                 pad = fmaxf(pad, fminf(x * k[6], __builtin_amdgcn_sqrtf(x) * 1.000001f));
             }
             for (uint32_t q = 0; q < P.n_pre_leaves; ++q) test_leaf<BIG, STATS>(sc, t, P.pre_leaf[q], st_sphere);
@@ -313,6 +354,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         uint32_t slot;
         const uint32_t n = pop(Q_E, 64u, slot);
         if (n == 0u) return false;
+        PF_COUNT(pl0);
+        PF_LANES(pl1, ballot(lane < n));
         const bool valid = lane < n;
         uint32_t best = kBestFresh, sw = 0u, lp = 0u, rp = 0u;
         if (valid) {
@@ -387,7 +430,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         }
         {
             const uint32_t ndead = (uint32_t)__popcll(ballot(dead));
-            if (ndead && lane == 0u) atomicSub(&ctrl_rw[C_LIVE], ndead);
+            if (ndead && lane == 0u) lds_fetch_sub(&ctrl_rw[C_LIVE], ndead);
         }
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 -------------------------------------------------------------
         const bool alive = valid && !dead;
@@ -453,6 +496,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
             n += n2;
         }
         if (n == 0u) return false;
+        PF_COUNT(pl2);
+        PF_LANES(pl3, ballot(lane < n));
         const bool valid = lane < n;
         V3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 0.0f);
         float tbest = 0.0f;
@@ -469,8 +514,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
             rng.k = fld(F_K, slot);
             rng.pixel = fld(F_RP, slot);
             rng.sample = fld(F_S, slot) & 0xffffu;
-            sraw = sc.spheres[best];
-            araw = sc.aux[best];
+            sraw = Scene<BIG>::ld(sc.spheres, best);
+            araw = Scene<BIG>::ld(sc.aux, best);
             rq = araw.w != 2u ? RQ_UNIT : RQ_WORD;
         }
         // unit vectors (Lambertian / Metallic) and the dielectric's draw, generated by the whole wave together
@@ -486,7 +531,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
             const bool front = vdot(d, outward) < 0.0f;
             const V3 N = front ? outward : vneg(outward);
             const uint32_t mh = araw.y;
-            const uint4 m0 = sc.mats[mh]; // {albedo, fuzz} or {refraction index, ...}
+            const uint4 m0 = Scene<BIG>::ld(sc.mats, mh); // {albedo, fuzz} or {refraction index, ...}
             const uint32_t kind = araw.w;
             bool scattered = true;
             if (kind != 2u) {
@@ -563,6 +608,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         const int target = 64 - (int)P.wf_refill;
         for (;;) {
             if (ctrl[C_ABORT] != 0u) break;
+            PF_MARK(pf2);
             // ---- hand finished segments over -------------------------------------------------------------------------
             {
                 const bool done = tst == 2u;
@@ -588,6 +634,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                 uint32_t popped;
                 got = pop(Q_T, n_idle, popped);
                 if (got != 0u) {
+                    PF_COUNT(pl6);
+#ifdef RTMI_PROF
+                    pl7 += got;
+#endif
                     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
                     const uint32_t mine = (uint32_t)__shfl((int)popped, (int)(r & 63u));
                     if (tst == 0u && r < got) {
@@ -608,6 +658,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                 }
             }
             const int n_act = (int)__popcll(ballot(tst == 1u));
+            PF_MARK(pf3);
             if (n_act == 0) {
                 if (ballot(tst == 2u) != 0ull) continue; // results to hand over
                 if (got == 0u) break;                     // nothing walking, nothing waiting: the episode is over
@@ -623,6 +674,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                 int n_leaf = (int)__popcll(m_leaf), n_node = (int)__popcll(m_node);
                 asm volatile("" : "+s"(n_leaf), "+s"(n_node));
                 if (n_leaf + n_node <= floor) break;
+                PF_COUNT(pl4);
+                PF_LANES(pl5, n_leaf > n_node ? m_leaf : m_node);
                 bool popit = false;
                 if (n_leaf > n_node) {
                     if (tst == 1u && at_leaf) {
@@ -630,11 +683,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                         popit = true;
                     }
                 } else if (tst == 1u && !at_leaf) {
-                    const uint4* np = sc.nodes + 4u * t.cur;
-                    const uint4 n0 = np[0];
-                    const uint4 n1 = np[1];
-                    const uint4 n2 = np[2];
-                    const uint4 n3 = np[3];
+                    const typename Scene<BIG>::Ptr np = sc.nodes + 4u * t.cur;
+                    const u32x4 n0 = np[0];
+                    const u32x4 n1 = np[1];
+                    const u32x4 n2 = np[2];
+                    const u32x4 n3 = np[3];
                     // rtmi_bvh_node: ctr[2][3] | half[2][3] | child[2] | reserved[2]
                     const float c0x = __uint_as_float(n0.x), c0y = __uint_as_float(n0.y), c0z = __uint_as_float(n0.z);
                     const float c1x = __uint_as_float(n0.w), c1y = __uint_as_float(n1.x), c1z = __uint_as_float(n1.y);
@@ -660,7 +713,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                     const bool nearer1 = tn1 < tn0;
                     const bool take1 = hit1 & (!hit0 | nearer1); // nearer child first
                     if (hit0 & hit1) {
-                        *reinterpret_cast<StackT*>(lds_raw + t.sp) = (StackT)(take1 ? ch0 : ch1);
+                        *(lds_stack_t*)(lds_raw + t.sp) = (StackT)(take1 ? ch0 : ch1);
                         t.sp += sp_stride;
                     }
                     t.cur = take1 ? ch1 : ch0; // overwritten by the pop when neither box is hit
@@ -668,7 +721,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                 }
                 if (popit) {
                     t.sp -= sp_stride;
-                    t.cur = *reinterpret_cast<const StackT*>(lds_raw + t.sp);
+                    t.cur = *(lds_stack_t*)(lds_raw + t.sp);
                     if (t.cur == kStackEnd) tst = 2u; // the sentinel: stack empty
                 }
             }
@@ -688,12 +741,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         else if (cE >= full) job = 2u;
         else if (cT >= full) job = 3u;
         bool did = false;
+        PF_MARK(pf4);
         if (job == 1u) {
             did = job_hit();
+            PF_MARK(pf1);
         } else if (job == 2u) {
             did = job_end();
+            PF_MARK(pf0);
         } else if (job == 3u) {
             mode_trav();
+            PF_MARK(pf2);
             did = true;
         }
         if (did) {
@@ -708,6 +765,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         }
     }
 
+#ifdef RTMI_PROF
+    PF_MARK(pf4);
+    if (lane == 0) {
+        unsigned long long* const pst = P.stats + 8;
+        atomicAdd(&pst[0], pf0); atomicAdd(&pst[1], pf1); atomicAdd(&pst[2], pf2); atomicAdd(&pst[3], pf3); atomicAdd(&pst[4], pf4);
+        atomicAdd(&pst[8], pl0); atomicAdd(&pst[9], pl1); atomicAdd(&pst[10], pl2); atomicAdd(&pst[11], pl3);
+        atomicAdd(&pst[12], pl4); atomicAdd(&pst[13], pl5); atomicAdd(&pst[14], pl6); atomicAdd(&pst[15], pl7);
+    }
+#endif
     if (ctrl[C_ABORT] != 0u && lane == 0u) atomicOr(P.wf_error, 1u);
     if (STATS) {
         atomicAdd(&P.stats[0], (unsigned long long)st_samples);

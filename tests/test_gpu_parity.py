@@ -340,6 +340,76 @@ def test_device_pointer_entry_and_sharded_blocks(pkg, ob, rtow, gpu):
             assert np.array_equal(frame8, want8)
 
 
+@pytest.mark.parametrize("tuning", [dict(kernel=2), dict(kernel=2, wf_block_lanes=512, wf_slots=320, wf_refill=8),
+                                    dict(kernel=2, wf_refill=56, blocks_per_cu=1), dict(kernel=2, force_hbm_scene=1)])
+def test_queue_scheduled_kernel_matches_oracle(pkg, ob, rtow, gpu, tuning):
+    """rtmi_tuning::kernel = 2 (rtmi_wavefront.hip: path slots and rings in LDS, waves take homogeneous batches): same
+    draw streams, same arithmetic -- the oracle's frame bit for bit, the oracle's work counters, for LDS- and
+    HBM-resident scenes, deep bounces, depth limits 0 and 1, ragged images, sharded row blocks and banded calls."""
+    torch = gpu
+    kw = dict(image_width=144, samples_per_pixel=12, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    W, H = cam.img_width, cam.img_height
+    want, want8 = ob.render_rect_counter(ocam, *rtow, 71, 0, 0, W, H, nthreads=8)
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=tuning) as s:
+        rgb, rgba = s.render_rows(0, H, 71)
+        st = s.stats()
+        part, _ = s.render_rows(5, 23, 71)
+        # sharded row blocks through the device-pointer entry
+        dev = torch.device("cuda", 0)
+        plan = pkg.RowShardPlan(H, 8, 3)
+        parts = []
+        for r in range(3):
+            y_first, n_blocks, rows = plan.shard(r)
+            buf = torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev)
+            s.render_row_blocks_device(y_first, 8, 3, n_blocks, 71, buf.data_ptr(), 0, torch.cuda.current_stream(dev).cuda_stream)
+            parts.append(buf)
+        torch.cuda.synchronize()
+        s.last_kernel_ms()  # also reads the watchdog word
+        frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev)).cpu().numpy()
+    _assert_frames_equal(rgb, want)
+    assert np.array_equal(rgba, want8)
+    _assert_frames_equal(part, want[5:23])
+    _assert_frames_equal(frame, want)
+    assert st["samples"] == H * W * 12
+    # deep bounces (config 5 shape) and a banded call
+    g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
+    ccam = pkg.camera_setup(pkg.camera_params(**json.loads(str(g["camera"]))))
+    with pkg.Scene(ccam, g["objects"], g["materials"], accel=pkg.ACCEL_BVH, tuning=dict(tuning, sample_buf_mb=1)) as s:
+        crgb, crgba = s.render_rows(0, ccam.img_height, int(g["seed"]))
+    _assert_frames_equal(crgb, g["rgb"])
+    assert np.array_equal(crgba, g["rgba"])
+    # depth limits 0 and 1, ragged sizes
+    objs, mats = three_spheres()
+    for (w, aspect, spp, depth) in ((33, 1.0, 5, 0), (65, 3.0, 9, 1), (100, 16.0 / 9.0, 17, 7)):
+        k3 = dict(three_spheres_camera(), image_width=w, aspect_ratio=aspect, samples_per_pixel=spp, max_depth=depth)
+        c3, o3 = pkg.camera_setup(pkg.camera_params(**k3)), ob.camera_setup(ob.camera_params(**k3))
+        w3, w38 = ob.render_rect_counter(o3, objs, mats, 4, 0, 0, c3.img_width, c3.img_height)
+        with pkg.Scene(c3, objs, mats, accel=pkg.ACCEL_BVH, tuning=tuning) as s:
+            r3, r38 = s.render_rows(0, c3.img_height, 4)
+        _assert_frames_equal(r3, w3)
+        assert np.array_equal(r38, w38)
+
+
+def test_queue_scheduled_kernel_statistics(pkg, ob, rtow, gpu):
+    """Work counters of the queue-scheduled kernel equal the oracle's instrumented walk of the same tree."""
+    kw = dict(image_width=96, samples_per_pixel=8, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    bvh = pkg.bvh_build(rtow[0])
+    obvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
+    _, _, ctr = ob.render_rect_counter(ocam, *rtow, 3, 0, 0, ocam.img_width, ocam.img_height, nthreads=8, counters=True, bvh=obvh)
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=dict(kernel=2)) as s:
+        s.render_rows(0, cam.img_height, 3)
+        st = s.stats()
+    assert st["samples"] == ctr["samples"] and st["segments"] == ctr["segments"]
+    # v_rcp_f32 in the (conservative) slab test against the oracle's true division: visit counts differ in the last digits
+    for k in ("sphere_tests", "node_tests"):
+        assert abs(st[k] - ctr[k]) <= 1e-3 * ctr[k], (k, st[k], ctr[k])
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=dict(kernel=1)) as s:
+        s.render_rows(0, cam.img_height, 3)
+        assert s.stats() == st  # the two kernels walk the same tree with the same arithmetic
+
+
 def test_multi_device_frame_entry_degenerate_one_device(pkg, ob, rtow, gpu):
     """rtmi_frame_* with n = 1 (what one box offers): shard plan of one rank, no communicator, de-interleave kernel run
     on the identity map -- the frame must be bit-equal to rtmi_render_rows and to the oracle; also with a block size that
@@ -567,6 +637,157 @@ def test_config5_cornell_full_resolution(pkg, ob, gpu):
     for x, y in zip(rng.integers(0, 800, 16), rng.integers(0, 800, 16)):
         want, _ = ob.render_rect_counter(ocam, objs, mats, 9, int(x), int(y), int(x) + 1, int(y) + 1)
         _assert_frames_equal(rgb[y, x][None, None], want)
+
+
+def _bvh_equals_scan(pkg, cam, objs, mats, seed, tunings=(None,)):
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BRUTE) as s:
+        want, _ = s.render_rows(0, cam.img_height, seed)
+    worst = 0
+    for tun in tunings:
+        with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=tun) as s:
+            got, _ = s.render_rows(0, cam.img_height, seed)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        worst = max(worst, int((~same).any(axis=-1).sum()))
+    return worst
+
+
+def _decades_world(pkg, seed, m=200):
+    """Radii over seven decades, three huge spheres: the regime where the pad's square-root bound matters."""
+    rng = np.random.default_rng(seed)
+    objs = np.zeros(m, pkg.OBJECT_DTYPE)
+    mats = np.zeros(m, pkg.MATERIAL_DTYPE)
+    objs["center"] = rng.normal(0.0, 30.0, (m, 3)).astype(np.float32)
+    objs["radius"] = (10.0 ** rng.uniform(-3.0, 1.5, m)).astype(np.float32)
+    objs["radius"][:3] = (1.0e3, 1.0e4, 3.0e2)
+    objs["center"][:3] = ((0.0, -1.0e3, 0.0), (0.0, 0.0, -1.2e4), (350.0, 0.0, 0.0))
+    objs["material"] = np.arange(m)
+    mats["kind"] = rng.integers(0, 3, m)
+    mats["p"] = rng.uniform(0.2, 1.0, (m, 4)).astype(np.float32)
+    mats["p"][mats["kind"] == 2, 0] = 1.5
+    return objs, mats
+
+
+def test_bvh_walk_equals_linear_scan_on_generated_worlds(pkg, gpu):
+    """The exactness claim of the BVH: for 36 generated worlds -- the reference's generator under other seeds,
+    random spheres of mixed radii, jittered grids over an R = 1e4 ground, radii over seven decades seen from 20 to 30 000
+    units away -- the walk (both kernels) and the linear scan give bit-identical frames."""
+    bad = {}
+    for i in range(36):
+        if i % 3 == 0:
+            objs, mats = pkg.make_world_spheres(1000 + i)
+            kw = dict(image_width=400, samples_per_pixel=12, max_depth=50)
+        elif i % 3 == 1:
+            objs, mats = random_spheres(300 + 40 * i, seed=i, extent=6.0 + i)
+            kw = dict(image_width=320, samples_per_pixel=8, max_depth=30)
+        elif i % 6 == 2:
+            objs, mats, kw = big_grid(24 + 4 * i, seed=i)
+            kw.update(image_width=240, samples_per_pixel=4)
+        else:
+            objs, mats = _decades_world(pkg, i)
+            far = (20.0, 2.0e3, 3.0e4)[(i // 6) % 3]
+            kw = dict(image_width=240, samples_per_pixel=8, max_depth=40, vertical_fov=50.0, defocus_angle=0.0,
+                      focus_distance=10.0, lookfrom=(far, 0.3 * far + 1.0, 0.5 * far), lookat=(0.0, 0.0, 0.0),
+                      world_up=(0.0, 1.0, 0.0))
+        cam = pkg.camera_setup(pkg.camera_params(**kw))
+        d = _bvh_equals_scan(pkg, cam, objs, mats, 77 + i, tunings=(dict(kernel=1), dict(kernel=2)))
+        if d:
+            bad[i] = d
+    assert not bad, bad
+
+
+def test_bvh_walk_equals_linear_scan_on_grazing_rays(pkg, gpu):
+    """Adversarial case for the box pad: every ray of the image grazes a sphere's limb inside the band where the fp32
+    discriminant of object.defs.cc:43-50 changes sign (half-width ~25 u max(L, R)^2 / 2R around the silhouette, u = 2^-24),
+    seen from 20 to 30 000 units away, for radii from 0.05 to 1000.  A sphere culled by a box that the scan would have
+    accepted shows up as a differing pixel."""
+    u = 2.0 ** -24
+    rng = np.random.default_rng(9)
+    objs, mats = _decades_world(pkg, 123, m=64)
+    checked = 0
+    for target in (3, 7, 11, 0, 2, 19, 33):  # small and huge spheres
+        C = objs["center"][target].astype(np.float64)
+        R = float(objs["radius"][target])
+        for L in (20.0, 1.0e3, 3.0e4):
+            if L <= 1.5 * R:
+                continue
+            view = rng.normal(size=3)
+            view /= np.linalg.norm(view)
+            O = C + L * view
+            side = np.cross(view, (0.0, 1.0, 0.0))
+            side /= np.linalg.norm(side)
+            limb = C + R * side  # a point of the silhouette as seen from O
+            band = 25.0 * u * max(L, R) ** 2 / (2.0 * R)
+            span = min(max(16.0 * band, 1e-5 * R), 3.0 * R)  # image height at the limb: +-8 bands around the silhouette
+            dist = float(np.linalg.norm(limb - O))
+            kw = dict(aspect_ratio=1.0, image_width=96, samples_per_pixel=4, max_depth=4,
+                      vertical_fov=float(np.degrees(2.0 * np.arctan(0.5 * span / dist))), defocus_angle=0.0,
+                      focus_distance=dist, lookfrom=tuple(float(v) for v in O), lookat=tuple(float(v) for v in limb),
+                      world_up=(0.0, 1.0, 0.0))
+            cam = pkg.camera_setup(pkg.camera_params(**kw))
+            d = _bvh_equals_scan(pkg, cam, objs, mats, 5, tunings=(dict(kernel=1), dict(kernel=2)))
+            assert d == 0, (target, R, L, d)
+            checked += 1
+    assert checked >= 15
+
+
+def test_config4_full_size(pkg, ob, gpu):
+    """BASELINE configs[3] at its own size: 99 857 spheres (scene in HBM), 1920x1080, 256 spp, 50 bounces.  The oracle
+    cannot render the frame (its linear scan needs ~0.5 s per PIXEL), so: the frame is reproducible, a row range and an
+    8-way interleaved row-block render give the same bits, and 12 pixels equal the oracle's linear scan."""
+    torch = gpu
+    objs, mats, kw = big_grid(316)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    W, H = cam.img_width, cam.img_height
+    assert (W, H, cam.samples_per_pixel, cam.maxdepth, len(objs)) == (1920, 1080, 256, 50, 316 * 316 + 1)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, device=0) as s:
+        full = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        s.render_row_blocks_device(0, H, 1, 1, 404, full.data_ptr(), 0, stream)
+        again = torch.zeros_like(full)
+        s.render_row_blocks_device(0, H, 1, 1, 404, again.data_ptr(), 0, stream)
+        part = torch.zeros((37, W, 3), dtype=torch.float32, device=dev)
+        s.render_row_blocks_device(611, 37, 1, 1, 404, part.data_ptr(), 0, stream)
+        plan = pkg.RowShardPlan(H, 8, 8)
+        parts = []
+        for r in range(8):
+            y_first, n_blocks, _ = plan.shard(r)
+            buf = torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev)
+            s.render_row_blocks_device(y_first, 8, 8, n_blocks, 404, buf.data_ptr(), 0, stream)
+            parts.append(buf)
+        torch.cuda.synchronize()
+        frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev))
+        bits = lambda t: torch.nan_to_num(t).view(torch.int32)
+        assert torch.equal(bits(again), bits(full))
+        assert torch.equal(bits(part), bits(full[611:648]))
+        assert torch.equal(bits(frame), bits(full))
+        host = full.cpu().numpy()
+    assert 0.05 < float(np.nanmean(host)) < 0.9
+    rng = np.random.default_rng(44)
+    for x, y in zip(rng.integers(0, W, 12), rng.integers(H // 3, H, 12)):  # the lower two thirds see the sphere field
+        want, _ = ob.render_rect_counter(ocam, objs, mats, 404, int(x), int(y), int(x) + 1, int(y) + 1)
+        _assert_frames_equal(host[y, x][None, None], want)
+
+
+def test_config5_full_size(pkg, ob, gpu):
+    """BASELINE configs[4] at its own size: 800x800, 4096 spp, 200 bounces.  Its 42 GB of sample records exceed the
+    library's 24 GB buffer cap, so the call runs in two bands of rows without any override; a row range rendered on
+    its own (one band) gives the same bits, and 16 pixels equal the oracle."""
+    objs, mats, kw = cornell_like()
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    assert (cam.img_width, cam.img_height, cam.samples_per_pixel, cam.maxdepth) == (800, 800, 4096, 200)
+    assert 800 * 800 * 4096 * 16 > 24 << 30  # needs the banded path
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as s:
+        rgb, rgba = s.render_rows(0, 800, 55)
+        assert s.last_kernel_ms() > 1000.0
+        part, part8 = s.render_rows(392, 408, 55)  # straddles the band boundary of the full call
+    assert rgb[392:408].tobytes() == part.tobytes() and np.array_equal(rgba[392:408], part8)
+    assert np.isfinite(rgb).all() and 0.001 < float(rgb.mean()) < 1.0  # a dark box: light enters through the opening only
+    rng = np.random.default_rng(45)
+    for x, y in zip(rng.integers(0, 800, 16), rng.integers(0, 800, 16)):
+        want, want8 = ob.render_rect_counter(ocam, objs, mats, 55, int(x), int(y), int(x) + 1, int(y) + 1)
+        _assert_frames_equal(rgb[y, x][None, None], want)
+        assert rgba[y, x] == want8[0, 0]
 
 
 @pytest.mark.parametrize("config", ["2", "3"])

@@ -70,15 +70,59 @@ def test_philox4x32_10_known_answers(ob, ctr, key, want):
     assert tuple(int(v) for v in o) == want
 
 
-def test_counter_stream_definition(ob):
-    """draw k of (seed, pixel, sample) = word k&3 of Philox({k>>2, sample, pixel, 0}, seed) * 2^-32."""
-    seed, pixel, sample = 0x1234567890ABCDEF, 4321, 17
-    key = np.array([seed & 0xffffffff, seed >> 32], np.uint32)
-    for k in range(11):
-        c = np.array([k >> 2, sample, pixel, 0], np.uint32)
+def _pcg4d_numpy(v):
+    """pcg4d of Jarzynski & Olano (JCGT 2020) + the output xorshift, on python ints (independent of the C restatement)."""
+    M, A, m32 = 1664525, 1013904223, 0xffffffff
+    x, y, z, w = [(int(c) * M + A) & m32 for c in v]
+    for _ in range(2):
+        x = (x + y * w) & m32
+        y = (y + z * x) & m32
+        z = (z + x * y) & m32
+        w = (w + y * z) & m32
+        x, y, z, w = x ^ (x >> 16), y ^ (y >> 16), z ^ (z >> 16), w ^ (w >> 16)
+    return x, y, z, w
+
+
+def test_pcg4d_matches_independent_restatement(ob):
+    rng = np.random.default_rng(3)
+    cases = [(0, 0, 0, 0), (1, 2, 3, 4), (0xffffffff,) * 4] + [tuple(int(v) for v in rng.integers(0, 2 ** 32, 4)) for _ in range(64)]
+    for v in cases:
+        i = np.array(v, np.uint32)
         o = np.zeros(4, np.uint32)
-        ob.lib().orc_philox4x32_10(c.ctypes.data, key.ctypes.data, o.ctypes.data)
-        assert ob.lib().orc_counter_double(seed, pixel, sample, k) == int(o[k & 3]) / 2.0 ** 32
+        ob.lib().orc_pcg4d(i.ctypes.data, o.ctypes.data)
+        assert tuple(int(c) for c in o) == _pcg4d_numpy(v), v
+
+
+def test_pcg4d_output_bits_are_balanced(ob):
+    """Why the output xorshift is there: over the pixels of a frame every bit of every word is one half of the time."""
+    n = 1 << 16
+    ones = np.zeros((4, 32))
+    for p in range(n):
+        o = _pcg4d_numpy((0, 5, p, 2025))
+        for wi in range(4):
+            ones[wi] += [(o[wi] >> b) & 1 for b in range(32)]
+    assert np.abs(ones / n - 0.5).max() < 0.01
+
+
+def test_counter_stream_definition(ob):
+    """draw k of (seed, pixel, sample) = word k&3 of block k>>2 = pcg4d(k>>2, sample ^ seed_hi, pixel, seed_lo), * 2^-32;
+    the Philox variants of the A/B (orc_set_counter_rng) use {k>>2, sample, pixel, 0} keyed by the seed."""
+    seed, pixel, sample = 0x1234567890ABCDEF, 4321, 17
+    assert ob.get_counter_rng() == 0  # the shipped block function
+    for k in range(11):
+        o = _pcg4d_numpy((k >> 2, sample ^ (seed >> 32), pixel, seed & 0xffffffff))
+        assert ob.lib().orc_counter_double(seed, pixel, sample, k) == o[k & 3] / 2.0 ** 32
+    key = np.array([seed & 0xffffffff, seed >> 32], np.uint32)
+    try:
+        for rounds in (10, 7):
+            ob.set_counter_rng(rounds)
+            for k in range(6):
+                c = np.array([k >> 2, sample, pixel, 0], np.uint32)
+                o = np.zeros(4, np.uint32)
+                ob.lib().orc_philox4x32(rounds, c.ctypes.data, key.ctypes.data, o.ctypes.data)
+                assert ob.lib().orc_counter_double(seed, pixel, sample, k) == int(o[k & 3]) / 2.0 ** 32
+    finally:
+        ob.set_counter_rng(0)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -50,6 +50,13 @@ if __name__ == "__main__":
             print(f"config3 wf {ms_b:.1f} ms ({n/ms_b/1e3:.0f} Ms/s)", flush=True)
             a, _, ms_a, n, _ = render(1920, 512, 50, dict(kernel=1), reps=2)
             print(f"config3: differing pixels {compare(a, b)}; legacy {ms_a:.1f} ms ({n/ms_a/1e3:.0f} Ms/s)", flush=True)
+        elif case == "others":
+            for scene, w, spp, d in (("cornell", 800, 64, 200), ("grid", 1920, 16, 50)):
+                a, _, ms_a, n, _ = render(w, spp, d, dict(kernel=1), reps=2, scene=scene)
+                b, _, ms_b, _, _ = render(w, spp, d, dict(kernel=2), reps=2, scene=scene)
+                c, _, ms_c, _, _ = render(w, spp, d, dict(kernel=2, wf_refill=40), reps=2, scene=scene)
+                print(f"{scene} {w} x {spp} spp: differing pixels {compare(a, b)} {compare(a, c)}; legacy {ms_a:.1f} ms ({n/ms_a/1e3:.0f} Ms/s)  "
+                      f"wf {ms_b:.1f} ms ({n/ms_b/1e3:.0f} Ms/s)  wf refill 40 {ms_c:.1f} ms ({n/ms_c/1e3:.0f} Ms/s)", flush=True)
         elif case.startswith("sweep"):
             w, spp = (1200, 100) if case == "sweep" else (1920, 256)
             for tun in (dict(kernel=1), dict(kernel=2), dict(kernel=2, wf_refill=16), dict(kernel=2, wf_refill=32), dict(kernel=2, wf_refill=40),
