@@ -110,7 +110,7 @@ typedef struct rtmi_tuning {
     uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 56) */
     uint32_t drain_wait_thresh; /* the same for the launch that finishes deferred paths (default 56) */
     int32_t chunk_samples;      /* samples per work item: 0 = auto, -1 = whole pixels (no sample records), n > 0 = n */
-    int32_t defer_mode;         /* deferred-path queue: 0 = auto (on for long launches), 1 = on, -1 = off */
+    int32_t defer_mode;         /* deferred-path queue + drain launch: 0 = default (off), 1 = on, 2 = on for long launches, -1 = off */
     uint32_t defer_cap;         /* capacity of that queue in records (default: 1/16 of the samples of the launch) */
     uint32_t sample_buf_mb;     /* cap on the sample-record buffer in MiB (default 24576); larger calls run in row bands */
     uint32_t force_hbm_scene;   /* nonzero: leave the scene in HBM even when it fits LDS (the config-4 path) */

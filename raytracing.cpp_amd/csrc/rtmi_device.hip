@@ -120,9 +120,20 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
     const uint32_t maxdepth = P.cam.maxdepth;
     uint32_t run_h = 0, run_n = 0;
     uint32_t npend = 0; // 1: a finished sample waits in `sum` for its partner of the same 32-byte sector
+    // LDS-resident scenes: closed runs go through a window of kAttLds (4) entries in LDS; a full window leaves as ONE
+    // 16-byte store to the lane's strip in HBM, so a path whose material changes at every bounce (the box of config 5:
+    // 79 segments per sample) moves 4 bytes per bounce instead of the two lone 4-byte stores it used to cost
+    // (rocprofv3 on config 5: 2.4 TB of write-backs per frame before).
+    const uint32_t att_blocks = (maxdepth + 3u) >> 2;
     auto att_store = [&](uint32_t q, uint32_t h, uint32_t n) {
-        if (!BIG && q < kAttLds) {
-            lds_att[q * blockDim.x + threadIdx.x] = h | (n << 16);
+        if (!BIG) {
+            const uint32_t e = h | (n << 16);
+            const uint32_t j = q & 3u;
+            lds_att[j * blockDim.x + threadIdx.x] = e;
+            if (j == 3u) {
+                reinterpret_cast<uint4*>(P.att_stack)[(size_t)glane * att_blocks + (q >> 2)] =
+                    make_uint4(lds_att[threadIdx.x], lds_att[blockDim.x + threadIdx.x], lds_att[2u * blockDim.x + threadIdx.x], e);
+            }
         } else {
             P.att_stack[((size_t)glane * maxdepth + q) * 2u] = h;
             P.att_stack[((size_t)glane * maxdepth + q) * 2u + 1u] = n;
@@ -510,7 +521,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                         ended = true; // the next compute_color call returns 0 (core.cc:238-240)
                     } else {
                         bool deferred = false;
-                        if (!DRAIN && !BIG && P.defer_buf && !front && kind != 2u && natt <= 4u && depth_left >= 8u) {
+                        if (!DRAIN && !BIG && P.defer_buf && !front && kind != 2u && natt < 4u && depth_left >= 8u) {
                             // wave-aggregated append to the deferred-path queue (ballot + prefix popcount)
                             const uint64_t m = ballot(true);
                             const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -566,17 +577,26 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                 const float tt = 0.5f * (unit_dir.y + 1.0f);
                 color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
                 color = att_apply(color, run_h, run_n);
-                for (uint32_t q = natt; q-- > 0u;) {
-                    uint32_t h, n;
-                    if (!BIG && q < kAttLds) {
-                        const uint32_t e = lds_att[q * blockDim.x + threadIdx.x];
-                        h = e & 0xffffu;
-                        n = e >> 16;
-                    } else {
-                        h = P.att_stack[((size_t)glane * maxdepth + q) * 2u];
-                        n = P.att_stack[((size_t)glane * maxdepth + q) * 2u + 1u];
+                if (!BIG) {
+                    const uint32_t full = natt >> 2; // whole windows that went to HBM; the rest is still in LDS
+                    for (uint32_t q = natt; q > 4u * full;) {
+                        --q;
+                        const uint32_t e = lds_att[(q & 3u) * blockDim.x + threadIdx.x];
+                        color = att_apply(color, e & 0xffffu, e >> 16);
                     }
-                    color = att_apply(color, h, n);
+                    for (uint32_t b = full; b-- > 0u;) {
+                        const uint4 blk = reinterpret_cast<const uint4*>(P.att_stack)[(size_t)glane * att_blocks + b];
+                        color = att_apply(color, blk.w & 0xffffu, blk.w >> 16);
+                        color = att_apply(color, blk.z & 0xffffu, blk.z >> 16);
+                        color = att_apply(color, blk.y & 0xffffu, blk.y >> 16);
+                        color = att_apply(color, blk.x & 0xffffu, blk.x >> 16);
+                    }
+                } else {
+                    for (uint32_t q = natt; q-- > 0u;) {
+                        const uint32_t h = P.att_stack[((size_t)glane * maxdepth + q) * 2u];
+                        const uint32_t n = P.att_stack[((size_t)glane * maxdepth + q) * 2u + 1u];
+                        color = att_apply(color, h, n);
+                    }
                 }
                 ended = true;
             }
@@ -758,7 +778,7 @@ struct rtmi_scene {
     hipEvent_t ev2 = nullptr;    // end of the trace kernels (ev1 = end of the launch, resolve included)
     uint4* d_defer = nullptr;    // deferred-path queue
     uint32_t defer_cap = 0;
-    int defer_mode = 2;        // 0 off, 1 on, 2 auto: on for launches long enough to pay for the second launch
+    int defer_mode = 0;        // 0 off (default since the cheaper draw streams: A/B in DESIGN.md), 1 on, 2 on for long launches
     uint32_t defer_cap_req = 0; // rtmi_tuning::defer_cap (0: sized from the launch)
     bool top_down = false;
     // launch geometry
@@ -1262,7 +1282,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     if (tune.blocks_per_cu) per_cu = std::max(1, std::min(per_cu, (int)tune.blocks_per_cu));
     if (tune.wait_thresh) s->wait_thresh = std::min(64u, tune.wait_thresh);
     if (tune.chunk_samples) s->chunk = tune.chunk_samples < 0 ? 0u : (uint32_t)tune.chunk_samples; // 0: split off
-    if (tune.defer_mode) s->defer_mode = tune.defer_mode > 0 ? 1 : 0;
+    if (tune.defer_mode) s->defer_mode = tune.defer_mode > 0 ? (tune.defer_mode == 2 ? 2 : 1) : 0;
     s->defer_cap_req = tune.defer_cap;
     if (tune.drain_wait_thresh) s->drain_wait_thresh = std::min(64u, tune.drain_wait_thresh);
     if (tune.sample_buf_mb) s->sample_buf_cap_bytes = (size_t)tune.sample_buf_mb << 20;

@@ -52,7 +52,6 @@ constexpr uint32_t kCellEmpty = 0xffffu;
 constexpr uint32_t kBestNone = 0xffffffffu, kBestBlack = 0xfffffffeu, kBestFresh = 0xfffffffdu;
 enum : uint32_t { C_LIVE = 8, C_ABORT = 9, C_POOLS = 16 }; // control words; [2q] head, [2q + 1] tail of ring q
 constexpr uint32_t kSpinLimit = 1u << 22;
-constexpr uint32_t kAttSlot = 2; // closed attenuation runs kept in the slot (LDS-resident scenes)
 
 // LDS-qualified pointer types: through generic pointers the volatile ring accesses become flat_* instructions with
 // system-scope cache bits and full waits (the address-space inference pass leaves volatile accesses alone)
@@ -186,6 +185,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
     uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0;
     PF_DECL
     const size_t gslot0 = (size_t)blockIdx.x * NS; // first slot of this workgroup in the HBM strip of attenuation runs
+    const uint32_t att_blocks = (maxdepth + 1u) >> 1; // 8-byte windows per slot in that strip
 
     auto fld = [&](uint32_t f, uint32_t slot) -> lds_u32& { return fields[f * NS + slot]; };
     auto raise_abort = [&]() { ctrl[C_ABORT] = 1u; };
@@ -294,10 +294,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         } else {
             if (c.run_n != 0u) { // close the open run
                 const uint32_t q = c.natt++;
-                if (!BIG && q == 0u) {
-                    c.att0 = c.run_h | (c.run_n << 16);
-                } else if (!BIG && q == 1u) {
-                    c.att1 = c.run_h | (c.run_n << 16);
+                if (!BIG) {
+                    // a window of two closed runs lives in the slot; a full window leaves as one 8-byte store
+                    const uint32_t e = c.run_h | (c.run_n << 16);
+                    if ((q & 1u) == 0u) {
+                        c.att0 = e;
+                    } else {
+                        c.att1 = e;
+                        reinterpret_cast<uint2*>(P.att_stack)[(gslot0 + slot) * att_blocks + (q >> 1)] = make_uint2(c.att0, e);
+                    }
                 } else {
                     P.att_stack[((gslot0 + slot) * maxdepth + q) * 2u] = c.run_h;
                     P.att_stack[((gslot0 + slot) * maxdepth + q) * 2u + 1u] = c.run_n;
@@ -356,6 +361,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         if (n == 0u) return false;
         PF_COUNT(pl0);
         PF_LANES(pl1, ballot(lane < n));
+        PF_MARK(pf4);
         const bool valid = lane < n;
         uint32_t best = kBestFresh, sw = 0u, lp = 0u, rp = 0u;
         if (valid) {
@@ -375,23 +381,27 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                 color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
                 const Chain c = chain_load(slot, fld(F_DEPTH, slot));
                 color = att_apply(color, c.run_h, c.run_n);
-                for (uint32_t q = c.natt; q-- > 0u;) {
-                    uint32_t h, cnt;
-                    if (!BIG && q < kAttSlot) {
-                        const uint32_t e = q == 0u ? c.att0 : c.att1;
-                        h = e & 0xffffu;
-                        cnt = e >> 16;
-                    } else {
-                        h = P.att_stack[((gslot0 + slot) * maxdepth + q) * 2u];
-                        cnt = P.att_stack[((gslot0 + slot) * maxdepth + q) * 2u + 1u];
+                if (!BIG) {
+                    const uint32_t full = c.natt >> 1; // whole windows that went to HBM
+                    if (c.natt & 1u) color = att_apply(color, c.att0 & 0xffffu, c.att0 >> 16);
+                    for (uint32_t b = full; b-- > 0u;) {
+                        const uint2 blk = reinterpret_cast<const uint2*>(P.att_stack)[(gslot0 + slot) * att_blocks + b];
+                        color = att_apply(color, blk.y & 0xffffu, blk.y >> 16);
+                        color = att_apply(color, blk.x & 0xffffu, blk.x >> 16);
                     }
-                    color = att_apply(color, h, cnt);
+                } else {
+                    for (uint32_t q = c.natt; q-- > 0u;) {
+                        const uint32_t h = P.att_stack[((gslot0 + slot) * maxdepth + q) * 2u];
+                        const uint32_t cnt = P.att_stack[((gslot0 + slot) * maxdepth + q) * 2u + 1u];
+                        color = att_apply(color, h, cnt);
+                    }
                 }
             }
             P.sample_buf[(size_t)lp * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
             s++;
             if (STATS) st_samples++;
         }
+        PF_MARK(pf5);
         // ---- next work item for the slots whose chunk is finished (one wave-aggregated atomic per round of requests) ---
         bool need = valid && (best == kBestFresh || s >= s_end);
         bool dead = false;
@@ -432,6 +442,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
             const uint32_t ndead = (uint32_t)__popcll(ballot(dead));
             if (ndead && lane == 0u) lds_fetch_sub(&ctrl_rw[C_LIVE], ndead);
         }
+        PF_MARK(pf6);
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 -------------------------------------------------------------
         const bool alive = valid && !dead;
         bool to_trav = false, to_end = false;
@@ -475,10 +486,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                 to_trav = true;
             }
         }
+        PF_MARK(pf7);
         begin_ray(to_trav, slot, origin, dir);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         push(Q_T, to_trav, slot);
         push(Q_E, to_end, slot);
+        PF_MARK(pf8);
         return true;
     };
 
@@ -498,6 +511,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
         if (n == 0u) return false;
         PF_COUNT(pl2);
         PF_LANES(pl3, ballot(lane < n));
+        PF_MARK(pf4);
         const bool valid = lane < n;
         V3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 0.0f);
         float tbest = 0.0f;
@@ -518,8 +532,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
             araw = Scene<BIG>::ld(sc.aux, best);
             rq = araw.w != 2u ? RQ_UNIT : RQ_WORD;
         }
+        PF_MARK(pf9);
         // unit vectors (Lambertian / Metallic) and the dielectric's draw, generated by the whole wave together
         const V3 unit_vec = coop_draws(rq, rng, P.seed, rank_tbl);
+        PF_MARK(pf10);
         bool to_trav = false, to_end = false;
         V3 p = mk(0.0f, 0.0f, 0.0f), sd = mk(0.0f, 0.0f, 0.0f);
         if (valid) {
@@ -589,10 +605,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
             }
             if (to_end) fld(F_BEST, slot) = kBestBlack;
         }
+        PF_MARK(pf11);
         begin_ray(to_trav, slot, p, sd);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         push(Q_T, to_trav, slot);
         push(Q_E, to_end, slot);
+        PF_MARK(pf1);
         return true;
     };
 
@@ -770,6 +788,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
     if (lane == 0) {
         unsigned long long* const pst = P.stats + 8;
         atomicAdd(&pst[0], pf0); atomicAdd(&pst[1], pf1); atomicAdd(&pst[2], pf2); atomicAdd(&pst[3], pf3); atomicAdd(&pst[4], pf4);
+        atomicAdd(&pst[5], pf5); atomicAdd(&pst[6], pf6); atomicAdd(&pst[7], pf7); atomicAdd(&pst[24], pf8); atomicAdd(&pst[25], pf9);
+        atomicAdd(&pst[26], pf10); atomicAdd(&pst[27], pf11);
         atomicAdd(&pst[8], pl0); atomicAdd(&pst[9], pl1); atomicAdd(&pst[10], pl2); atomicAdd(&pst[11], pl3);
         atomicAdd(&pst[12], pl4); atomicAdd(&pst[13], pl5); atomicAdd(&pst[14], pl6); atomicAdd(&pst[15], pl7);
     }

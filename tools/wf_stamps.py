@@ -21,11 +21,12 @@ with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=tun) as sc:
     ms = sc.last_kernel_ms()
     out = (C.c_ulonglong * 64)()
     pkg.lib().rtmi_prof_read(sc._h, out)
-v = [int(x) for x in out[8:32]]
-tot = sum(v[:5])
+v = [int(x) for x in out[8:40]]
+tot = sum(v[:8]) + sum(v[24:28])
 print(f"{tun}: kernel {ms:.1f} ms; stamped cycles {tot:.3e}")
-for name, x in zip(["job_end", "job_hit", "walk", "handover+refill", "sched/idle"], v[:5]):
-    print(f"  {name:16s} {x:16d} {100.0 * x / tot:6.2f} %")
+names = ["job_end tail", "job_hit: begin_ray+push", "walk", "handover+refill", "sched/idle + pops", "job_end: colour+store", "job_end: work fetch", "job_end: gen"]
+for name, x in list(zip(names, v[:8])) + list(zip(["job_end: begin_ray+push", "job_hit: loads", "job_hit: coop draws", "job_hit: shade"], v[24:28])):
+    print(f"  {name:26s} {x:16d} {100.0 * x / tot:6.2f} %")
 je, jel, jh, jhl, wi, wl, rf, rfl = v[8:16]
 print(f"  job_end  x{je}: {jel / max(1, je):.1f} lanes, {v[0] / max(1, je):.0f} cycles each")
 print(f"  job_hit  x{jh}: {jhl / max(1, jh):.1f} lanes, {v[1] / max(1, jh):.0f} cycles each")
