@@ -48,10 +48,12 @@
 //              32-bit entries (config 4: 100k spheres, 2.4 MB of spheres + 6.4 MB of nodes).
 // DRAIN = true: the launch that finishes the deferred paths (work items are queue records; no primary rays, no
 // chunk bookkeeping, no further deferral) -- same arithmetic, leaner control flow.
-template <int ACCEL, bool STATS, bool BIG, bool DRAIN>
+template <int ACCEL, bool STATS, bool BIG, int MODE>
 // 6 waves per SIMD (<= 80 VGPRs): two workgroups of 768 lanes per CU; that occupancy is worth +17 % over 4 waves per
 // SIMD (measured), and one register more would silently halve it -- hence the explicit bound
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
+    // MODE 0: plain launch; 1: launch that may defer paths to the queue; 2: the launch that drains the queue
+    constexpr bool DRAIN = MODE == 2, DEFER = MODE == 1;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
     // traversal stack: entry 0 of every lane holds a sentinel that ends the walk when it is popped
@@ -521,7 +523,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
                         ended = true; // the next compute_color call returns 0 (core.cc:238-240)
                     } else {
                         bool deferred = false;
-                        if (!DRAIN && !BIG && P.defer_buf && !front && kind != 2u && natt < 4u && depth_left >= 8u) {
+                        if (DEFER && !BIG && P.defer_buf && !front && kind != 2u && natt < 4u && depth_left >= 8u) {
                             // wave-aggregated append to the deferred-path queue (ballot + prefix popcount)
                             const uint64_t m = ballot(true);
                             const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -648,7 +650,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(102
         PF_MARK(pf3);
     }
 
-    if (!DRAIN && P.defer_buf && lane == 0u) { // reserved but unused slots become empty records (depth 0)
+    if (DEFER && P.defer_buf && lane == 0u) { // reserved but unused slots become empty records (depth 0)
         for (uint32_t q = pool[2]; q < pool[3]; ++q) {
             if (q < P.defer_cap) P.defer_buf[(size_t)q * 5u + 2u] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -808,8 +810,8 @@ using KernelFn = void (*)(const RtmiLaunch);
 
 template <int ACCEL>
 KernelFn pick_variant(bool stats, bool big) {
-    if (big) return stats ? rtmi_trace_kernel<ACCEL, true, true, false> : rtmi_trace_kernel<ACCEL, false, true, false>;
-    return stats ? rtmi_trace_kernel<ACCEL, true, false, false> : rtmi_trace_kernel<ACCEL, false, false, false>;
+    if (big) return stats ? rtmi_trace_kernel<ACCEL, true, true, 0> : rtmi_trace_kernel<ACCEL, false, true, 0>;
+    return stats ? rtmi_trace_kernel<ACCEL, true, false, 0> : rtmi_trace_kernel<ACCEL, false, false, 0>;
 }
 
 KernelFn pick_kernel(uint32_t accel, bool stats, bool big) {
@@ -818,7 +820,12 @@ KernelFn pick_kernel(uint32_t accel, bool stats, bool big) {
 
 // the drain launch exists for LDS-resident BVH scenes only (that is where paths are deferred)
 KernelFn pick_drain_kernel(bool stats) {
-    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, false, true> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, false, true>;
+    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, false, 2> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, false, 2>;
+}
+
+// the primary launch of a call that defers paths (LDS-resident BVH scenes only)
+KernelFn pick_defer_kernel(bool stats) {
+    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, false, 1> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, false, 1>;
 }
 
 void free_scene(rtmi_scene* s) {
@@ -997,7 +1004,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         const int rc = rtmi_wavefront_launch(P, s->collect_stats, s->big, s->wf_wpe, s->wf_grid, s->wf_block, s->wf_lds_bytes, stream);
         if (rc != RTMI_OK) return rc;
     } else {
-        KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big);
+        KernelFn fn = P.defer_buf ? pick_defer_kernel(s->collect_stats) : pick_kernel(s->accel, s->collect_stats, s->big);
         void* args[] = {&P};
         HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
     }
@@ -1269,6 +1276,8 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
                                   (int)s->lds_bytes));
     if (!s->big && s->accel == RTMI_ACCEL_BVH) {
         HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_drain_kernel(s->collect_stats)),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+        HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_defer_kernel(s->collect_stats)),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
     }
     int per_cu = 0;
