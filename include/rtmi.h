@@ -107,7 +107,7 @@ typedef struct rtmi_tuning {
     uint32_t struct_size;       /* = sizeof(rtmi_tuning) */
     uint32_t block_lanes;       /* lanes per workgroup, multiple of 64 (default 768: 2 x 768 per CU = 6 waves per SIMD) */
     uint32_t blocks_per_cu;     /* cap on resident workgroups per CU (default: the occupancy query) */
-    uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 56) */
+    uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 52) */
     uint32_t drain_wait_thresh; /* the same for the launch that finishes deferred paths (default 56) */
     int32_t chunk_samples;      /* samples per work item: 0 = auto, -1 = whole pixels (no sample records), n > 0 = n */
     int32_t defer_mode;         /* deferred-path queue + drain launch: 0 = default (off), 1 = on, 2 = on for long launches, -1 = off */

@@ -786,7 +786,9 @@ struct rtmi_scene {
     // launch geometry
     uint32_t block = 768, grid = 0, lds_bytes = 0, stack_depth = 0; // 2 x 768 lanes per CU = 6 waves per SIMD (<= 80 VGPRs)
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
-    uint32_t wait_thresh = 56; // lanes waiting for shading that end a traversal round (A/B on MI355X: 56 best)
+    // lanes waiting for shading that end a traversal round (A/B on MI355X, round 2: 52 = 56 on the LDS-resident RTOW
+    // scene, 3.5 % better than 56 on the HBM-resident 100k-sphere scene; 62 costs that scene 23 %)
+    uint32_t wait_thresh = 52;
     uint32_t lds_att = 0, lds_pool = 0;
     uint32_t drain_wait_thresh = 56;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
