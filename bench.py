@@ -270,18 +270,35 @@ def main(argv=None):
         scene = pkg.Scene(cam, objs, mats, accel=accel, device=local_rank)
         plan = pkg.RowShardPlan(H, BLOCK_ROWS, world)
         y_first, n_blocks, rows = plan.shard(rank)
-        rgb = torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev)
-        rgba = torch.zeros((plan.max_rows, W, 1), dtype=torch.int32, device=dev)
+        # one buffer per rank -- float RGB then RGBA8 (as bits) -- so that the frame travels in ONE collective
+        n_px = plan.max_rows * W
+        local = torch.zeros(n_px * 4, dtype=torch.float32, device=dev)
+        rgb = local[:n_px * 3].view(plan.max_rows, W, 3)
+        rgba = local[n_px * 3:].view(torch.int32).view(plan.max_rows, W, 1)
+
+        def split(parts):
+            """[world * n_px * 4] gathered floats -> (rgb frame, rgba frame) in scanline order"""
+            per = parts.view(world, n_px * 4)
+            idx = torch.as_tensor(plan.index, device=parts.device)
+            f = per[:, :n_px * 3].reshape(world * plan.max_rows, W, 3).index_select(0, idx)
+            f8 = per[:, n_px * 3:].reshape(world * plan.max_rows, W, 1).view(torch.int32).index_select(0, idx)
+            return f, f8
 
         def step():
             if n_blocks:
                 scene.render_row_blocks_device(y_first, BLOCK_ROWS, world, n_blocks, RENDER_SEED, rgb.data_ptr(),
                                                rgba.data_ptr(), stream)
-            if world > 1 and dist.get_backend() != "nccl":  # rehearsal backend: stage through host memory
+            if world == 1:
+                return rgb[:H], rgba[:H]
+            if dist.get_backend() != "nccl":  # rehearsal backend: stage through host memory
                 torch.cuda.synchronize(dev)
-                f, f8 = pkg.gather_frame(rgb.cpu(), plan, rank), pkg.gather_frame(rgba.cpu(), plan, rank)
-                return (f.to(dev), f8.to(dev)) if rank == 0 else (None, None)
-            return pkg.gather_frame(rgb, plan, rank), pkg.gather_frame(rgba, plan, rank)
+                host = local.cpu()
+                got = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, got, dst=0)
+                return split(torch.cat(got).to(dev)) if rank == 0 else (None, None)
+            got = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+            dist.gather(local, got, dst=0)  # the one RCCL collective of a frame
+            return split(torch.cat(got)) if rank == 0 else (None, None)
 
     def sync():
         torch.cuda.synchronize(dev)

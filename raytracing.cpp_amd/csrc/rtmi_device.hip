@@ -43,6 +43,10 @@
 
 #include "rtmi_kernel_common.h"
 
+#ifndef RTMI_WPE
+#define RTMI_WPE 6 // waves per SIMD the register allocation aims at (A/B: 7 = 72 VGPRs + 20 B of scratch, 4 % slower)
+#endif
+
 // BIG = false: the whole scene is staged into LDS and stack entries are packed into 16 bits (<= 8192 spheres).
 // BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
 //              32-bit entries (config 4: 100k spheres, 2.4 MB of spheres + 6.4 MB of nodes).
@@ -51,7 +55,7 @@
 template <int ACCEL, bool STATS, bool BIG, int MODE>
 // 6 waves per SIMD (<= 80 VGPRs): two workgroups of 768 lanes per CU; that occupancy is worth +17 % over 4 waves per
 // SIMD (measured), and one register more would silently halve it -- hence the explicit bound
-__global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
+__global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     // MODE 0: plain launch; 1: launch that may defer paths to the queue; 2: the launch that drains the queue
     constexpr bool DRAIN = MODE == 2, DEFER = MODE == 1;
     extern __shared__ __align__(16) unsigned char lds_raw[];
