@@ -498,15 +498,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                         scattered = vdot(sd, N) > 0.0f;
                     }
                 } else { // Material_Dielectric::scatter, material.defs.cc:57-87
-                    const float ri = __uint_as_float(m0.x);
-                    const float eta = front ? (1.0f / ri) : ri;
+                    // eta = front ? 1/ri : ri and r1 = ((1 - eta) / (1 + eta))^2 (material.defs.cc:58, 80-82) depend on the
+                    // material and the face only: both pairs are computed once on the host with the same fp32 operations
+                    const float eta = front ? __uint_as_float(m0.y) : __uint_as_float(m0.x);
+                    const float r1 = front ? __uint_as_float(m0.z) : __uint_as_float(m0.w);
                     const V3 unit_dir = vnormalize(t.d);
                     const float cos_theta = fminf(vdot(vneg(unit_dir), N), 1.0f);
                     const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
                     bool reflect_it = (eta * sin_theta) > 1.0f;
                     if (!reflect_it) { // short-circuit ||: the draw happens only when refraction is possible
-                        const float r0 = (1.0f - eta) / (1.0f + eta);
-                        const float r1 = r0 * r0;
                         // powf(x, 5): x^5 through double is the correctly rounded value except for ties
                         const double xd = (double)(1.0f - cos_theta);
                         const double x2 = xd * xd;
@@ -1192,7 +1192,16 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     }
     for (uint32_t i = 0; i < n_materials; ++i) {
         const rtmi_material& m = materials[i];
-        h_mats[i] = make_uint4(fbits(m.p[0]), fbits(m.p[1]), fbits(m.p[2]), fbits(m.p[3]));
+        if (m.kind == 2u) {
+            // Material_Dielectric::scatter, material.defs.cc:58 and :80-82: eta and the Schlick r1 for both faces, with the
+            // operations (and roundings) the per-hit code would use
+            const float ri = m.p[0];
+            const float eta_front = 1.0f / ri;
+            const float r0f = (1.0f - eta_front) / (1.0f + eta_front), r0b = (1.0f - ri) / (1.0f + ri);
+            h_mats[i] = make_uint4(fbits(ri), fbits(eta_front), fbits(r0f * r0f), fbits(r0b * r0b));
+        } else {
+            h_mats[i] = make_uint4(fbits(m.p[0]), fbits(m.p[1]), fbits(m.p[2]), fbits(m.p[3]));
+        }
     }
 
     if (tune.block_lanes) s->block = std::min(1024u, std::max(64u, (tune.block_lanes / 64u) * 64u));

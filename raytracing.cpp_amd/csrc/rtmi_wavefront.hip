@@ -564,15 +564,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                     scattered = vdot(sd, N) > 0.0f;
                 }
             } else { // Material_Dielectric::scatter, material.defs.cc:57-87
-                const float ri = __uint_as_float(m0.x);
-                const float eta = front ? (1.0f / ri) : ri;
+                // eta = front ? 1/ri : ri and r1 = ((1 - eta) / (1 + eta))^2 (material.defs.cc:58, 80-82) depend on the
+                // material and the face only: both pairs are computed once on the host with the same fp32 operations
+                const float eta = front ? __uint_as_float(m0.y) : __uint_as_float(m0.x);
+                const float r1 = front ? __uint_as_float(m0.z) : __uint_as_float(m0.w);
                 const V3 unit_dir = vnormalize(d);
                 const float cos_theta = fminf(vdot(vneg(unit_dir), N), 1.0f);
                 const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
                 bool reflect_it = (eta * sin_theta) > 1.0f;
                 if (!reflect_it) { // short-circuit ||: the draw happens only when refraction is possible
-                    const float r0 = (1.0f - eta) / (1.0f + eta);
-                    const float r1 = r0 * r0;
                     // powf(x, 5): x^5 through double is the correctly rounded value except for ties
                     const double xd = (double)(1.0f - cos_theta);
                     const double x2 = xd * xd;
