@@ -376,16 +376,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                         pop = true;
                     }
                 } else if (phase == PH_TRAV && !at_leaf) {
-                    const uint4* np = lds_nodes + 4u * t.cur; // config 4: read through L2 / Infinity Cache
-                    const uint4 n0 = np[0];
-                    const uint4 n1 = np[1];
-                    const uint4 n2 = np[2];
-                    const uint4 n3 = np[3];
-                    // rtmi_bvh_node: ctr[2][3] | half[2][3] | child[2] | reserved[2]
-                    const float c0x = __uint_as_float(n0.x), c0y = __uint_as_float(n0.y), c0z = __uint_as_float(n0.z);
-                    const float c1x = __uint_as_float(n0.w), c1y = __uint_as_float(n1.x), c1z = __uint_as_float(n1.y);
-                    const float h0x = __uint_as_float(n1.z), h0y = __uint_as_float(n1.w), h0z = __uint_as_float(n2.x);
-                    const float h1x = __uint_as_float(n2.y), h1y = __uint_as_float(n2.z), h1z = __uint_as_float(n2.w);
+                    NodeFields nd;
+                    if (BIG) { // 48-byte records read through L1 / L2 / Infinity Cache (config 4)
+                        const uint4* np = lds_nodes + 3u * t.cur;
+                        const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
+                        nd = unpack_node48(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z);
+                    } else { // 64-byte records in LDS
+                        const uint4* np = lds_nodes + 4u * t.cur;
+                        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                        nd = unpack_node64(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y);
+                    }
+                    const float c0x = nd.c0x, c0y = nd.c0y, c0z = nd.c0z, c1x = nd.c1x, c1y = nd.c1y, c1z = nd.c1z;
+                    const float h0x = nd.h0x, h0y = nd.h0y, h0z = nd.h0z, h1x = nd.h1x, h1y = nd.h1y, h1z = nd.h1z;
                     const float ax = __builtin_fabsf(t.inv.x), ay = __builtin_fabsf(t.inv.y), az = __builtin_fabsf(t.inv.z);
                     // slab test in centre/half form: the pad rides in the FMA of the half extent
                     const float tc0x = __builtin_fmaf(c0x, t.inv.x, t.oinv.x), th0x = __builtin_fmaf(h0x, ax, t.pinv.x);
@@ -401,7 +403,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     const float tf1 = fminf(fminf(tc1x + th1x, tc1y + th1y), fminf(tc1z + th1z, t.tbest));
                     if (STATS) st_node += 2;
                     const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
-                    const uint32_t ch0 = n3.x, ch1 = n3.y;
+                    const uint32_t ch0 = nd.ch0, ch1 = nd.ch1;
                     asm volatile("" ::"v"(ch0), "v"(ch1)); // keep the child-reference read with the box reads (one LDS round trip)
                     // flat on purpose: selects instead of nested branches (each nesting level is an exec-mask
                     // save / restore and a branch of the wave)
@@ -1282,7 +1284,48 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
             }
             if (s->n_pre_leaves) s->root_ref_dev = (cur == kNoWalk) ? kNoWalk : (s->big ? cur : pack16(cur));
         }
-        HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
+        if (s->big && !dn.empty()) {
+            // 48-byte records: centres fp32, half extents fp16 rounded up (an extent beyond fp16 becomes +inf: always hit),
+            // child references.  The exported tree (rtmi_scene_get_bvh) carries the rounded extents, so that an instrumented
+            // CPU walk tests the same boxes.
+            auto half_up = [](float v) -> uint16_t {
+                _Float16 h = (_Float16)v; // round to nearest
+                if ((float)h < v) {        // bump to the next fp16 above
+                    uint16_t bits;
+                    std::memcpy(&bits, &h, 2);
+                    bits = (uint16_t)(bits + 1u); // v > 0 here: the next representable value (or +inf)
+                    std::memcpy(&h, &bits, 2);
+                }
+                uint16_t out;
+                std::memcpy(&out, &h, 2);
+                return out;
+            };
+            auto half_to_float = [](uint16_t b) {
+                _Float16 h;
+                std::memcpy(&h, &b, 2);
+                return (float)h;
+            };
+            std::vector<uint32_t> rec(dn.size() * 12u, 0u);
+            for (size_t i = 0; i < dn.size(); ++i) {
+                uint32_t* r = &rec[i * 12u];
+                for (int k = 0; k < 2; ++k)
+                    for (int a = 0; a < 3; ++a) r[k * 3 + a] = fbits(dn[i].ctr[k][a]);
+                uint16_t hb[6];
+                for (int k = 0; k < 2; ++k)
+                    for (int a = 0; a < 3; ++a) {
+                        hb[k * 3 + a] = half_up(std::max(dn[i].half[k][a], 0.0f));
+                        s->bvh.nodes[i].half[k][a] = half_to_float(hb[k * 3 + a]);
+                    }
+                r[6] = hb[0] | ((uint32_t)hb[1] << 16);
+                r[7] = hb[2] | ((uint32_t)hb[3] << 16);
+                r[8] = hb[4] | ((uint32_t)hb[5] << 16);
+                r[9] = dn[i].child[0];
+                r[10] = dn[i].child[1];
+            }
+            HIP_TRY_S(upload(&s->d_nodes, rec.data(), rec.size() * sizeof(uint32_t)));
+        } else {
+            HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
+        }
     }
 
     // persistent grid: exactly as many workgroups as the device keeps resident

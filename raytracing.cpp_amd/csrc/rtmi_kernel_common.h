@@ -94,6 +94,37 @@ DEV uint32_t fdiv(uint32_t n, const FastDiv f) {
     return (t1 + ((n - t1) >> f.sh1)) >> f.sh2;
 }
 
+// HBM-resident scenes (BIG kernels) read 48-byte node records: both centres fp32, the six half extents fp16 (rounded up
+// on the host), two child references.  Config 4 is bound by the rate of its node reads, not by their latency (touching
+// the children one step ahead made it 32 % slower): three 16-byte reads per step instead of four.
+struct NodeFields {
+    float c0x, c0y, c0z, c1x, c1y, c1z, h0x, h0y, h0z, h1x, h1y, h1z;
+    uint32_t ch0, ch1;
+};
+DEV float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+DEV float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+DEV NodeFields unpack_node48(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b0, uint32_t b1, uint32_t b2,
+                             uint32_t b3, uint32_t c0, uint32_t c1, uint32_t c2) {
+    NodeFields n;
+    n.c0x = __uint_as_float(a0); n.c0y = __uint_as_float(a1); n.c0z = __uint_as_float(a2);
+    n.c1x = __uint_as_float(a3); n.c1y = __uint_as_float(b0); n.c1z = __uint_as_float(b1);
+    n.h0x = half_lo(b2); n.h0y = half_hi(b2); n.h0z = half_lo(b3);
+    n.h1x = half_hi(b3); n.h1y = half_lo(c0); n.h1z = half_hi(c0);
+    n.ch0 = c1; n.ch1 = c2;
+    return n;
+}
+DEV NodeFields unpack_node64(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b0, uint32_t b1, uint32_t b2,
+                             uint32_t b3, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t d0, uint32_t d1) {
+    NodeFields n; // rtmi_bvh_node: ctr[2][3] | half[2][3] | child[2] | reserved[2]
+    n.c0x = __uint_as_float(a0); n.c0y = __uint_as_float(a1); n.c0z = __uint_as_float(a2);
+    n.c1x = __uint_as_float(a3); n.c1y = __uint_as_float(b0); n.c1z = __uint_as_float(b1);
+    n.h0x = __uint_as_float(b2); n.h0y = __uint_as_float(b3); n.h0z = __uint_as_float(c0);
+    n.h1x = __uint_as_float(c1); n.h1y = __uint_as_float(c2); n.h1z = __uint_as_float(c3);
+    n.ch0 = d0; n.ch1 = d1;
+    return n;
+}
+
+
 // In-kernel stamps (diagnostic build only, -DRTMI_PROF): s_memtime deltas per phase of the v1 kernel, summed per wave
 // into stats[8 + i].  Never compiled into the shipped library.
 #ifdef RTMI_PROF

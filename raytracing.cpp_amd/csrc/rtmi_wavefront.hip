@@ -701,16 +701,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                         popit = true;
                     }
                 } else if (tst == 1u && !at_leaf) {
-                    const typename Scene<BIG>::Ptr np = sc.nodes + 4u * t.cur;
-                    const u32x4 n0 = np[0];
-                    const u32x4 n1 = np[1];
-                    const u32x4 n2 = np[2];
-                    const u32x4 n3 = np[3];
-                    // rtmi_bvh_node: ctr[2][3] | half[2][3] | child[2] | reserved[2]
-                    const float c0x = __uint_as_float(n0.x), c0y = __uint_as_float(n0.y), c0z = __uint_as_float(n0.z);
-                    const float c1x = __uint_as_float(n0.w), c1y = __uint_as_float(n1.x), c1z = __uint_as_float(n1.y);
-                    const float h0x = __uint_as_float(n1.z), h0y = __uint_as_float(n1.w), h0z = __uint_as_float(n2.x);
-                    const float h1x = __uint_as_float(n2.y), h1y = __uint_as_float(n2.z), h1z = __uint_as_float(n2.w);
+                    NodeFields nd;
+                    if (BIG) { // 48-byte records (half extents fp16), see rtmi_kernel_common.h
+                        const typename Scene<BIG>::Ptr np = sc.nodes + 3u * t.cur;
+                        const u32x4 n0 = np[0], n1 = np[1], n2 = np[2];
+                        nd = unpack_node48(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z);
+                    } else {
+                        const typename Scene<BIG>::Ptr np = sc.nodes + 4u * t.cur;
+                        const u32x4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                        nd = unpack_node64(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y);
+                    }
+                    const float c0x = nd.c0x, c0y = nd.c0y, c0z = nd.c0z, c1x = nd.c1x, c1y = nd.c1y, c1z = nd.c1z;
+                    const float h0x = nd.h0x, h0y = nd.h0y, h0z = nd.h0z, h1x = nd.h1x, h1y = nd.h1y, h1z = nd.h1z;
                     const float ax = __builtin_fabsf(t.inv.x), ay = __builtin_fabsf(t.inv.y), az = __builtin_fabsf(t.inv.z);
                     // slab test in centre/half form: the pad rides in the FMA of the half extent
                     const float tc0x = __builtin_fmaf(c0x, t.inv.x, t.oinv.x), th0x = __builtin_fmaf(h0x, ax, t.pinv.x);
@@ -726,7 +728,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WPE, WPE))) __launch_bounds__
                     const float tf1 = fminf(fminf(tc1x + th1x, tc1y + th1y), fminf(tc1z + th1z, t.tbest));
                     if (STATS) st_node += 2;
                     const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
-                    const uint32_t ch0 = n3.x, ch1 = n3.y;
+                    const uint32_t ch0 = nd.ch0, ch1 = nd.ch1;
                     asm volatile("" ::"v"(ch0), "v"(ch1)); // keep the child-reference read with the box reads
                     const bool nearer1 = tn1 < tn0;
                     const bool take1 = hit1 & (!hit0 | nearer1); // nearer child first

@@ -26,6 +26,7 @@ if "--build" in sys.argv:
         print("built", lib_path(name))
     sys.exit(0)
 w, spp = 1920, 512
+GRID = "--grid" in sys.argv
 objs = mats = None
 ref = None
 rows = []
@@ -33,9 +34,14 @@ for rnd in range(2):
     for name, flags, tuning in specs:
         pkg._lib = None
         pkg.LIB_PATH = lib_path(name)
-        if objs is None:
-            objs, mats = pkg.make_world_spheres(12345)
-        cam = pkg.camera_setup(pkg.camera_params(image_width=w, samples_per_pixel=spp, max_depth=50))
+        if GRID:
+            objs, mats, kw = pkg.workloads.big_grid(316)
+            kw.update(samples_per_pixel=32)
+            cam = pkg.camera_setup(pkg.camera_params(**kw))
+        else:
+            if objs is None:
+                objs, mats = pkg.make_world_spheres(12345)
+            cam = pkg.camera_setup(pkg.camera_params(image_width=w, samples_per_pixel=spp, max_depth=50))
         with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=tuning or None) as sc:
             ms = []
             for _ in range(2):
