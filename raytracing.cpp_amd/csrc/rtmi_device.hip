@@ -115,6 +115,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     Rng rng{};
     Trav t{};
+    t.cur = kStackEnd; // "not walking" (see the traversal loop)
     uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0;
     PF_DECL
 
@@ -351,15 +352,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
             // leave when wait_thresh lanes wait for shading; the stragglers keep their state and go on next round
             // (A/B on MI355X: counting finished lanes as waiting too was 0-5 % slower).  Inside the loop lanes only move
             // from TRAV to SHADE, so the test is on the number still traversing: no third vote, no reload per trip.
-            const int trav_floor = (int)__popcll(ballot(phase == PH_TRAV || phase == PH_SHADE)) - (int)P.wait_thresh;
+            // A lane walks iff its t.cur is a node or a leaf reference: a finished walk leaves the sentinel there (and lanes
+            // that never walked start with it), so the two votes come straight from t.cur -- no phase compare, no mask
+            // algebra in the loop (every instruction of this loop, scalar ones included, is paid ~15 times per round:
+            // ten more s_add per trip cost the frame 4.3 %, ten more v_mov 2.8 %, measured).
+            constexpr uint32_t kLeafLo = BIG ? kLeafBit : 0x8000u;           // leaf references start here ...
+            constexpr uint32_t kLeafSpan = BIG ? 0x7ffffffeu : 0x7fffu;      // ... and end below the markers / the sentinel
+            const int trav_floor = max(0, (int)__popcll(ballot(phase == PH_TRAV || phase == PH_SHADE)) - (int)P.wait_thresh);
             for (;;) {
-                // LDS-resident scenes carry their node/leaf references in the 16-bit form of the stack entries
-                // (0x8000 | (count-1) << 13 | first slot for a leaf): no packing or unpacking on push / pop
-                const bool at_leaf = t.cur >= (BIG ? kLeafBit : 0x8000u);
-                const uint64_t m_trav = ballot(phase == PH_TRAV);
-                const uint64_t m_leaf = ballot(at_leaf) & m_trav;
-                const uint64_t m_node = m_trav & ~m_leaf;
-                if (m_trav == 0ull) break;
+                const bool at_leaf = (t.cur ^ kLeafLo) < kLeafSpan, at_node = t.cur < kLeafLo;
+                const uint64_t m_leaf = ballot(at_leaf);
+                const uint64_t m_node = ballot(at_node);
                 PF_COUNT(pf11);
 #ifdef RTMI_PROF
                 if (__popcll(m_leaf) > __popcll(m_node)) { PF_COUNT(pl0); PF_LANES(pl1, m_leaf); } else { PF_LANES(pl2, m_node); }
@@ -368,14 +371,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                 // keep the counts 32-bit scalars: left alone the compiler compares the 64-bit popcounts, for which
                 // the scalar unit has no greater-than, and moves the vote's outcome through the vector unit
                 asm volatile("" : "+s"(n_leaf), "+s"(n_node));
-                if (n_leaf + n_node <= trav_floor) break;
+                if (n_leaf + n_node <= trav_floor) break; // also: nobody walks
                 bool pop = false;
                 if (n_leaf > n_node) {
-                    if (phase == PH_TRAV && at_leaf) {
+                    if (at_leaf) {
                         test_leaf(t.cur);
                         pop = true;
                     }
-                } else if (phase == PH_TRAV && !at_leaf) {
+                } else if (at_node) {
                     NodeFields nd;
                     if (BIG) { // 48-byte records read through L1 / L2 / Infinity Cache (config 4)
                         const uint4* np = lds_nodes + 3u * t.cur;
