@@ -372,6 +372,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                 // the scalar unit has no greater-than, and moves the vote's outcome through the vector unit
                 asm volatile("" : "+s"(n_leaf), "+s"(n_node));
                 if (n_leaf + n_node <= trav_floor) break; // also: nobody walks
+                // (one merged pop behind both branches: writing it out in each of them was measured 3 % slower)
                 bool pop = false;
                 if (n_leaf > n_node) {
                     if (at_leaf) {
@@ -401,9 +402,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     const float tc1z = __builtin_fmaf(c1z, t.inv.z, t.oinv.z), th1z = __builtin_fmaf(h1z, az, t.pinv.z);
                     // fmaxf/fminf drop a NaN operand (0 * inf on an axis-parallel ray), which keeps the test conservative
                     const float tn0 = fmaxf(fmaxf(tc0x - th0x, tc0y - th0y), fmaxf(tc0z - th0z, 0.0001f));
-                    const float tf0 = fminf(fminf(tc0x + th0x, tc0y + th0y), fminf(tc0z + th0z, t.tbest));
+                    // (the far limit goes in through one hand-placed v_min_f32 per box: fminf on a value the compiler cannot
+                    // prove quiet costs a canonicalising v_max_f32 per trip; tbest is +inf or a finite root)
+                    float zf0 = tc0z + th0z, zf1 = tc1z + th1z;
+                    asm("v_min_f32 %0, %1, %2" : "=v"(zf0) : "v"(zf0), "v"(t.tbest));
+                    asm("v_min_f32 %0, %1, %2" : "=v"(zf1) : "v"(zf1), "v"(t.tbest));
+                    const float tf0 = fminf(fminf(tc0x + th0x, tc0y + th0y), zf0);
                     const float tn1 = fmaxf(fmaxf(tc1x - th1x, tc1y - th1y), fmaxf(tc1z - th1z, 0.0001f));
-                    const float tf1 = fminf(fminf(tc1x + th1x, tc1y + th1y), fminf(tc1z + th1z, t.tbest));
+                    const float tf1 = fminf(fminf(tc1x + th1x, tc1y + th1y), zf1);
                     if (STATS) st_node += 2;
                     const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
                     const uint32_t ch0 = nd.ch0, ch1 = nd.ch1;
@@ -412,10 +418,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     // save / restore and a branch of the wave)
                     const bool nearer1 = tn1 < tn0;
                     const bool take1 = hit1 & (!hit0 | nearer1); // nearer child first (bitwise: no short-circuit branches)
-                    if (hit0 & hit1) {
-                        *reinterpret_cast<StackT*>(lds_raw + t.sp) = (StackT)(take1 ? ch0 : ch1);
-                        t.sp += sp_stride;
-                    }
+                    // the far child is written above the stack top unconditionally (the stack has one spare level) and only
+                    // counts when both boxes are hit: no exec-mask save / restore around the push
+                    *reinterpret_cast<StackT*>(lds_raw + t.sp) = (StackT)(take1 ? ch0 : ch1);
+                    t.sp += (hit0 & hit1) ? sp_stride : 0u;
                     t.cur = take1 ? ch1 : ch0; // overwritten by the pop when neither box is hit
                     pop = !(hit0 | hit1);
                 }
@@ -1213,7 +1219,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     // LDS carve-up.  Small scenes live in LDS entirely (two workgroups per CU must fit: 80 KiB each); larger ones
     // stay in HBM and only the traversal stack is in LDS.
     auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-    s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) + 1u : 0u; // + the sentinel entry
+    s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) + 2u : 0u; // + the sentinel entry + one spare level (unconditional push store)
     const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 16u;
     const uint64_t small_total = scene_bytes + (uint64_t)s->stack_depth * s->block * 2u + 64u;
     s->big = small_total + kAttLds * s->block * 4u > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u ||
