@@ -264,7 +264,17 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
     uint64_t todo = ballot(pending);
     while (todo != 0ull) {
         const uint32_t n = (uint32_t)__popcll(todo);
-        const uint32_t per = min(64u / n, 8u); // attempts per pending lane in this pass
+        // attempts per pending lane in this pass: min(64 / n, 8) as a compare chain (an integer division by a run-time
+        // value is a dozen instructions) together with the bits c * n, c < per, of the acceptance vote
+        uint32_t per = 1u;
+        uint64_t stride_mask = 1ull;
+        if (n <= 32u) {
+            per = n > 21u ? 2u : n > 16u ? 3u : n > 12u ? 4u : n > 10u ? 5u : n > 9u ? 6u : n > 8u ? 7u : 8u;
+            stride_mask |= 1ull << n;                                   // c = 0, 1
+            if (per > 2u) stride_mask |= stride_mask << (2u * n);        // c = 0..3   (per >= 3 => 4 n <= 84: bits past 63 fall off)
+            if (per > 4u) stride_mask |= stride_mask << (4u * n);        // c = 0..7   (per >= 5 => n <= 12)
+            if (per * n < 64u) stride_mask &= (1ull << (per * n)) - 1ull; // keep c < per
+        }
         const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
         if (pending) tbl[my_rank] = (uint8_t)lane; // rank -> lane of the pending stream
         // this lane evaluates attempt `a` of the pending lane of rank `r`
@@ -294,8 +304,6 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
         const uint64_t okm = ballot(ok);
         // the pending lane takes its first accepted attempt, in attempt order: its attempts sit at bits
         // my_rank + c * n (c < per) of the vote
-        uint64_t stride_mask = 0ull;
-        for (uint32_t c = 0; c < per; ++c) stride_mask |= 1ull << (c * n); // wave-uniform
         const uint64_t hits = (okm >> my_rank) & stride_mask;
         const bool found = pending && hits != 0ull;
         const uint32_t pos = (uint32_t)__builtin_ctzll(hits | (1ull << 63));
