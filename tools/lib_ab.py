@@ -27,6 +27,7 @@ if "--build" in sys.argv:
     sys.exit(0)
 w, spp = 1920, 512
 GRID = "--grid" in sys.argv
+CORNELL = "--cornell" in sys.argv
 objs = mats = None
 ref = None
 rows = []
@@ -34,7 +35,11 @@ for rnd in range(2):
     for name, flags, tuning in specs:
         pkg._lib = None
         pkg.LIB_PATH = lib_path(name)
-        if GRID:
+        if CORNELL:
+            objs, mats, kw = pkg.workloads.cornell_like()
+            kw.update(samples_per_pixel=256)
+            cam = pkg.camera_setup(pkg.camera_params(**kw))
+        elif GRID:
             objs, mats, kw = pkg.workloads.big_grid(316)
             kw.update(samples_per_pixel=32)
             cam = pkg.camera_setup(pkg.camera_params(**kw))
