@@ -131,21 +131,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
     // 16-byte store to the lane's strip in HBM, so a path whose material changes at every bounce (the box of config 5:
     // 79 segments per sample) moves 4 bytes per bounce instead of the two lone 4-byte stores it used to cost
     // (rocprofv3 on config 5: 2.4 TB of write-backs per frame before).
-    // The window holds att_win (4, 8 or 16) runs, as many as LDS has room for: a 16-run window leaves as one whole 64-byte
-    // line per lane.
-    const uint32_t att_win = P.att_win, att_mask = att_win - 1u;
-    const uint32_t att_strip = (maxdepth + att_mask) & ~att_mask; // dwords per lane in the HBM strip
+    const uint32_t att_blocks = (maxdepth + 3u) >> 2;
     auto att_store = [&](uint32_t q, uint32_t h, uint32_t n) {
         if (!BIG) {
             const uint32_t e = h | (n << 16);
-            const uint32_t j = q & att_mask;
+            const uint32_t j = q & 3u;
             lds_att[j * blockDim.x + threadIdx.x] = e;
-            if (j == att_mask) { // window full
-                uint4* dst = reinterpret_cast<uint4*>(P.att_stack + (size_t)glane * att_strip + (q - att_mask));
-                for (uint32_t k = 0; k < att_win; k += 4u) {
-                    dst[k >> 2] = make_uint4(lds_att[k * blockDim.x + threadIdx.x], lds_att[(k + 1u) * blockDim.x + threadIdx.x],
-                                             lds_att[(k + 2u) * blockDim.x + threadIdx.x], lds_att[(k + 3u) * blockDim.x + threadIdx.x]);
-                }
+            if (j == 3u) {
+                reinterpret_cast<uint4*>(P.att_stack)[(size_t)glane * att_blocks + (q >> 2)] =
+                    make_uint4(lds_att[threadIdx.x], lds_att[blockDim.x + threadIdx.x], lds_att[2u * blockDim.x + threadIdx.x], e);
             }
         } else {
             P.att_stack[((size_t)glane * maxdepth + q) * 2u] = h;
@@ -601,14 +595,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                 color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
                 color = att_apply(color, run_h, run_n);
                 if (!BIG) {
-                    const uint32_t full = natt & ~att_mask; // runs in whole windows that went to HBM; the rest is still in LDS
-                    for (uint32_t q = natt; q > full;) {
+                    const uint32_t full = natt >> 2; // whole windows that went to HBM; the rest is still in LDS
+                    for (uint32_t q = natt; q > 4u * full;) {
                         --q;
-                        const uint32_t e = lds_att[(q & att_mask) * blockDim.x + threadIdx.x];
+                        const uint32_t e = lds_att[(q & 3u) * blockDim.x + threadIdx.x];
                         color = att_apply(color, e & 0xffffu, e >> 16);
                     }
-                    for (uint32_t q = full; q > 0u; q -= 4u) {
-                        const uint4 blk = *reinterpret_cast<const uint4*>(P.att_stack + (size_t)glane * att_strip + (q - 4u));
+                    for (uint32_t b = full; b-- > 0u;) {
+                        const uint4 blk = reinterpret_cast<const uint4*>(P.att_stack)[(size_t)glane * att_blocks + b];
                         color = att_apply(color, blk.w & 0xffffu, blk.w >> 16);
                         color = att_apply(color, blk.z & 0xffffu, blk.z >> 16);
                         color = att_apply(color, blk.y & 0xffffu, blk.y >> 16);
@@ -810,7 +804,7 @@ struct rtmi_scene {
     // lanes waiting for shading that end a traversal round (A/B on MI355X, round 2: 52 = 56 on the LDS-resident RTOW
     // scene, 3.5 % better than 56 on the HBM-resident 100k-sphere scene; 62 costs that scene 23 %)
     uint32_t wait_thresh = 52;
-    uint32_t lds_att = 0, lds_pool = 0, att_win = kAttLds;
+    uint32_t lds_att = 0, lds_pool = 0;
     uint32_t drain_wait_thresh = 56;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     uint32_t pre_leaf_dev[4] = {}; // leaves peeled off the top of the tree, tested at segment set-up
@@ -920,7 +914,6 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.lds_nodes = s->lds_nodes;
     P.lds_stack = s->lds_stack;
     P.lds_att = s->lds_att;
-    P.att_win = s->att_win;
     P.lds_pool = s->lds_pool;
     P.stack_depth = s->stack_depth;
     P.y_first = y_first;
@@ -1248,18 +1241,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     off += s->stack_depth * s->block * (s->big ? 4u : 2u);
     off = align16(off);
     s->lds_att = off;
-    if (!s->big) {
-        // attenuation window: 16 runs per lane where LDS has room (two workgroups per CU: 80 KiB each), else 8, else 4
-        const uint32_t rest = (s->block / 64u) * 80u + 64u;
-        s->att_win = kAttLds;
-        for (uint32_t w = 16u; w > kAttLds; w >>= 1) {
-            if (off + w * s->block * 4u + rest <= 80u * 1024u) {
-                s->att_win = w;
-                break;
-            }
-        }
-        off += s->att_win * s->block * 4u;
-    }
+    if (!s->big) off += kAttLds * s->block * 4u;
     s->lds_pool = off; // per wave: {work_next, work_end, slot_next, slot_end}
     off += (s->block / 64u) * 80u; // + 64-byte rank table of coop_draws
     s->lds_bytes = align16(off);
@@ -1432,8 +1414,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 64 * sizeof(unsigned long long)));
     HIP_TRY_S(hipMemset(s->d_stats, 0, 64 * sizeof(unsigned long long)));
     const size_t att_lanes = std::max<size_t>((size_t)s->grid * s->block, (size_t)s->wf_grid * s->wf_slots);
-    // per lane: two dwords per bounce (HBM-resident scenes) or one per bounce rounded up to whole windows
-    const size_t att_bytes = std::max<size_t>(16, ((size_t)camera->maxdepth * 2u + 16u) * att_lanes * sizeof(uint32_t));
+    const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * att_lanes * 2u * sizeof(uint32_t));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_att), att_bytes));
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY_S(hipEventCreate(&s->ev0));

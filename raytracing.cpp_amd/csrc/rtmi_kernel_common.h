@@ -72,7 +72,6 @@ struct RtmiLaunch {
     uint32_t* att_stack; // [lane][maxdepth] {handle, count}: attenuation runs that did not fit LDS
     unsigned long long* stats; // {samples, segments, sphere_tests, node_tests}
     // queue-scheduled kernel (rtmi_wavefront.hip): path slots, rings and control words in LDS
-    uint32_t att_win;       // round-based kernel: closed attenuation runs per lane in LDS (4, 8 or 16: what LDS has room for)
     uint32_t wf_slots;      // path slots per workgroup
     uint32_t wf_cap_mask;   // ring capacity - 1 (power of two >= wf_slots)
     uint32_t lds_wf_fields, lds_wf_rings, lds_wf_ctrl;
