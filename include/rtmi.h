@@ -228,7 +228,10 @@ typedef struct rtmi_frame_timing {
 } rtmi_frame_timing;
 
 /* `options->device` is ignored (the list decides); `devices` = HIP ordinals, distinct, 1 <= n <= 16;
- * `block_rows` = rows per shard block (0 = 8). */
+ * `block_rows` = rows per shard block (0 = 8).  Test hook: options->reserved[0] & RTMI_FRAME_REHEARSAL lets a device
+ * appear more than once and gathers the slices with plain copies instead of RCCL (which wants one rank per device), so
+ * that a one-GPU box can check the shard plan and the scanline order for n > 1. */
+#define RTMI_FRAME_REHEARSAL 1u
 int rtmi_frame_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
                       const rtmi_material* materials, uint32_t n_materials, const rtmi_scene_options* options,
                       const int32_t* devices, uint32_t n_devices, uint32_t block_rows, rtmi_frame** out);

@@ -325,10 +325,12 @@ class Frame:
     """Owns an rtmi_frame handle: one frame on several GPUs of one node, one process (rtmi_frame_*): scene replicas,
     interleaved row-block shards, one RCCL gather to devices[0]."""
 
-    def __init__(self, cam, objs, mats, devices=(0,), block_rows=8, accel=ACCEL_AUTO, leaf_size=0, tuning=None):
+    def __init__(self, cam, objs, mats, devices=(0,), block_rows=8, accel=ACCEL_AUTO, leaf_size=0, tuning=None,
+                 rehearsal=False):
         objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
         mats = np.ascontiguousarray(mats, dtype=MATERIAL_DTYPE)
         opt, _tun = _options(accel, leaf_size, -1, False, tuning)
+        opt.reserved[0] = 1 if rehearsal else 0  # RTMI_FRAME_REHEARSAL: repeated devices, copies instead of RCCL
         devs = (C.c_int32 * len(devices))(*devices)
         self._h = C.c_void_p()
         self.width, self.height, self.n_devices = cam.img_width, cam.img_height, len(devices)

@@ -89,6 +89,7 @@ struct Shard {
 
 struct rtmi_frame {
     uint32_t n = 0, W = 0, H = 0, block_rows = 8, max_rows = 0;
+    bool rehearsal = false; // test hook: devices may repeat, slices are gathered with copies instead of RCCL
     std::vector<int> devices;
     std::vector<rtmi_scene*> scenes;
     std::vector<hipStream_t> streams;
@@ -170,12 +171,17 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
                       const int32_t* devices, uint32_t n, uint32_t block_rows, rtmi_frame*& f) {
     int n_visible = 0;
     HIPF(hipGetDeviceCount(&n_visible));
+    rtmi_scene_options opt{};
+    opt.device = -1;
+    if (options) std::memcpy(&opt, options, std::min<size_t>(sizeof(opt), options->struct_size));
+    opt.struct_size = sizeof(opt);
+    const bool rehearsal = (opt.reserved[0] & 1u) != 0u; // RTMI_FRAME_REHEARSAL
     for (uint32_t i = 0; i < n; ++i) {
         if (devices[i] < 0 || devices[i] >= n_visible) {
             set_error("rtmi_frame_create: device ordinal outside the visible devices");
             return RTMI_ERR_BAD_ARG;
         }
-        for (uint32_t j = 0; j < i; ++j) {
+        for (uint32_t j = 0; j < i && !rehearsal; ++j) {
             if (devices[j] == devices[i]) {
                 set_error("rtmi_frame_create: the same device listed twice (RCCL needs one rank per device)");
                 return RTMI_ERR_BAD_ARG;
@@ -188,6 +194,7 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
         return RTMI_ERR_OOM;
     }
     f->n = n;
+    f->rehearsal = rehearsal;
     f->W = camera->img_width;
     f->H = camera->img_height;
     f->block_rows = block_rows ? block_rows : 8u;
@@ -214,10 +221,6 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
         index[y] = r * f->max_rows + k * B + (y - b * B);
     }
 
-    rtmi_scene_options opt{};
-    opt.device = -1;
-    if (options) std::memcpy(&opt, options, std::min<size_t>(sizeof(opt), options->struct_size));
-    opt.struct_size = sizeof(opt);
     const size_t slice_px = (size_t)std::max(1u, f->max_rows) * std::max(1u, W);
     for (uint32_t i = 0; i < n; ++i) {
         HIPF(hipSetDevice(devices[i]));
@@ -241,6 +244,8 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
     if (n > 1) {
         HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgb_gather), slice_px * n * 3 * sizeof(float)));
         HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgba_gather), slice_px * n * sizeof(uint32_t)));
+    }
+    if (n > 1 && !rehearsal) {
         RcclApi& api = rccl_api();
         if (!api.error.empty() || !api.Gather) {
             set_error("rtmi_frame_create: " + (api.error.empty() ? std::string("librccl unusable") : api.error));
@@ -248,7 +253,7 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
         }
         f->comms.assign(n, nullptr);
         NCCLF(api.CommInitAll(f->comms.data(), (int)n, f->devices.data()));
-    } else {
+    } else if (n == 1) {
         f->d_rgb_gather = f->d_rgb_slice[0];
         f->d_rgba_gather = f->d_rgba_slice[0];
     }
@@ -268,7 +273,19 @@ int frame_render_impl(rtmi_frame* f, uint64_t seed) {
     }
     HIPF(hipSetDevice(f->devices[0]));
     HIPF(hipEventRecord(f->ev_g0, f->streams[0]));
-    if (n > 1) {
+    if (n > 1 && f->rehearsal) {
+        // test hook: the same plan with plain copies, so that one box can check the shard and scanline-order arithmetic
+        const size_t slice_px = (size_t)f->max_rows * W;
+        for (uint32_t i = 0; i < n; ++i) {
+            HIPF(hipSetDevice(f->devices[i]));
+            HIPF(hipStreamSynchronize(f->streams[i]));
+            HIPF(hipMemcpyAsync(f->d_rgb_gather + (size_t)i * slice_px * 3, f->d_rgb_slice[i], slice_px * 3 * sizeof(float),
+                                hipMemcpyDeviceToDevice, f->streams[0]));
+            HIPF(hipMemcpyAsync(f->d_rgba_gather + (size_t)i * slice_px, f->d_rgba_slice[i], slice_px * sizeof(uint32_t),
+                                hipMemcpyDeviceToDevice, f->streams[0]));
+        }
+        HIPF(hipSetDevice(f->devices[0]));
+    } else if (n > 1) {
         // ONE gather of the dense slices to devices[0]: every rank's call sits in one group, on its own stream, behind its
         // own kernels
         RcclApi& api = rccl_api();

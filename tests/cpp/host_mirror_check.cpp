@@ -85,14 +85,21 @@ int main(int argc, char** argv) {
         if (mode == "frame" && argc >= 6) {
             auto core = RayTracingCore::setup(wd, seed);
             const uint64_t rseed = std::strtoull(argv[4], nullptr, 10);
-            const int n_dev = argc >= 7 ? std::atoi(argv[6]) : 1;
+            // n_devices > 0: devices 0..n-1 (RCCL gather for n > 1); n_devices < 0: device 0 listed |n| times through the
+            // rehearsal hook (copies instead of RCCL), what a one-GPU box can check of the n > 1 plumbing
+            const int n_arg = argc >= 7 ? std::atoi(argv[6]) : 1;
+            const int n_dev = n_arg < 0 ? -n_arg : n_arg;
             std::vector<int32_t> devices;
-            for (int d = 0; d < n_dev; ++d) devices.push_back(d);
+            for (int d = 0; d < n_dev; ++d) devices.push_back(n_arg < 0 ? 0 : d);
+            rtmi_scene_options fopt{};
+            fopt.struct_size = sizeof(fopt);
+            fopt.device = -1;
+            if (n_arg < 0) fopt.reserved[0] = RTMI_FRAME_REHEARSAL;
             const size_t n = size_t(core->rts_img_width) * core->rts_img_height;
             std::vector<RGBAColor> want(n), got(n);
             std::vector<float> want_rgb(n * 3), got_rgb(n * 3);
             if (core->raytrace_rows(0, core->rts_img_height, rseed, want.data(), want_rgb.data()) != RTMI_OK) return 4;
-            if (core->attach_devices(devices, 8) != RTMI_OK) {
+            if (core->attach_devices(devices, 8, &fopt) != RTMI_OK) {
                 std::fprintf(stderr, "attach_devices: %s\n", rtmi_last_error());
                 return 5;
             }

@@ -432,6 +432,13 @@ def test_multi_device_frame_entry_degenerate_one_device(pkg, ob, rtow, gpu):
             assert d_rgb and d_rgba
             torch.cuda.synchronize()
         assert rgb.tobytes() == ref.tobytes() and np.array_equal(rgba, ref8)
+    # n > 1 on one box: the rehearsal hook lists the device several times and gathers with copies instead of RCCL; the
+    # shard plan (interleaved blocks, ragged last block), the rank-major gather layout and the scanline order are the real ones
+    for devices, block_rows in (((0, 0), 8), ((0, 0, 0), 5), ((0,) * 8, 8), ((0,) * 7, 3)):
+        with pkg.Frame(cam, *rtow, devices=devices, block_rows=block_rows, rehearsal=True) as f:
+            rgb, rgba = f.render(21)
+            assert f.rccl_ranks == 0 and len(f.timing()["kernel_ms"]) == len(devices)
+        assert rgb.tobytes() == ref.tobytes() and np.array_equal(rgba, ref8), (devices, block_rows)
     n_dev = torch.cuda.device_count()
     for devices in ((0, 0), (n_dev,), (-1,)):
         with pytest.raises(pkg.RtmiError) as e:

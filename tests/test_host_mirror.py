@@ -118,6 +118,9 @@ def test_attached_devices_frame_and_multi_worker_tracer(exe, ob, tmp_path):
     out = str(tmp_path / "frame8.bin")
     r = subprocess.run([exe, "frame", cfg, "12345", "78", out, "1"], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr)
+    # three shards and three workers on the one device (rehearsal hook: copies instead of RCCL)
+    r = subprocess.run([exe, "frame", cfg, "12345", "78", out, "-3"], capture_output=True, text=True)
+    assert r.returncode == 0 and "devices 3" in r.stdout, (r.returncode, r.stdout, r.stderr)
     ocam = ob.camera_setup(ob.camera_params(image_width=104, samples_per_pixel=4, max_depth=20))
     objs, mats = ob.make_world_spheres(12345, ob.world_def(), _fixed_from_json())
     _, want8 = ob.render_rect_counter(ocam, objs, mats, 78, 0, 0, 104, ocam.img_height, nthreads=8)
