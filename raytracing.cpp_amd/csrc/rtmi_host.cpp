@@ -478,10 +478,48 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
     out.pad_eps = 64.0f * 5.9604645e-8f;
     out.pad_floor = std::max(16.0f * 5.9604645e-8f * maxabs, 1e-6f);
     out.n_pad_classes = 0;
-    if (n) {
+    // Spheres in the leaves that the kernels peel off the top of the tree (the same spine rule as rtmi_scene_create: up to
+    // four leaves hanging directly off the root path) are tested at segment set-up, never through a box: they need no pad,
+    // and leaving them out usually removes a whole radius class (the ground sphere of the RTOW scene) from the per-segment
+    // pad computation.
+    std::vector<char> peeled(n, 0);
+    if (n && !out.nodes.empty()) {
+        uint32_t cur = out.root_ref, n_pre = 0;
+        auto mark = [&](uint32_t leaf) {
+            const uint32_t first = leaf & 0x00ffffffu, cnt = (leaf >> 24) & 0x7fu;
+            for (uint32_t q = 0; q < cnt; ++q) peeled[out.slot_object[first + q]] = 1;
+        };
+        while (!(cur & kLeafBit) && n_pre < 4u) {
+            const rtmi_bvh_node& nd = out.nodes[cur];
+            const bool l0 = (nd.child[0] & kLeafBit) != 0u, l1 = (nd.child[1] & kLeafBit) != 0u;
+            if (l0 && l1 && n_pre + 2u <= 4u) {
+                mark(nd.child[0]);
+                mark(nd.child[1]);
+                break;
+            }
+            if (l0 == l1) break;
+            mark(l0 ? nd.child[0] : nd.child[1]);
+            ++n_pre;
+            cur = l0 ? nd.child[1] : nd.child[0];
+        }
+    }
+    rmin_all = std::numeric_limits<float>::infinity();
+    rmax_all = 0.0f;
+    uint32_t n_boxed = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (peeled[i]) continue;
+        const float r = std::fabs(objects[i].radius);
+        rmin_all = std::min(rmin_all, r);
+        rmax_all = std::max(rmax_all, r);
+        ++n_boxed;
+    }
+    if (n_boxed) {
         const float l0 = std::log2(std::max(rmin_all, 1e-30f));
         const float l1 = std::log2(std::max(rmax_all, 1e-30f));
-        const float step = (l1 - l0) / static_cast<float>(kMaxPadClasses);
+        // one class per three octaves of radius, at most kMaxPadClasses: every class costs each ray segment ~23 vector
+        // instructions, and within a factor 8 the smallest radius of a class pads the others' boxes by little more
+        const uint32_t n_cls = std::min<uint32_t>(kMaxPadClasses, std::max(1u, static_cast<uint32_t>(std::ceil((l1 - l0) / 3.0f))));
+        const float step = (l1 - l0) / static_cast<float>(n_cls);
         Box cb[kMaxPadClasses];
         float rmin[kMaxPadClasses];
         float rmax[kMaxPadClasses] = {};
@@ -491,11 +529,11 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
             rmin[k] = std::numeric_limits<float>::infinity();
         }
         for (uint32_t i = 0; i < n; ++i) {
+            if (peeled[i]) continue;
             const float r = std::max(std::fabs(objects[i].radius), 1e-30f);
             uint32_t k = 0;
             if (step > 0.0f) {
-                k = static_cast<uint32_t>(std::min(std::max((std::log2(r) - l0) / step, 0.0f),
-                                                   static_cast<float>(kMaxPadClasses - 1)));
+                k = static_cast<uint32_t>(std::min(std::max((std::log2(r) - l0) / step, 0.0f), static_cast<float>(n_cls - 1)));
             }
             used[k] = true;
             rmin[k] = std::min(rmin[k], r);
