@@ -210,7 +210,19 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
             // walls of a box made of huge spheres -- are tested here, by all the lanes that start a segment, and the
             // walk begins below them with the far limit already set: one node trip and one leaf trip less per leaf
             // and segment.  A tree that is nothing but such a spine is not walked at all.
-            for (uint32_t q = 0; q < P.n_pre_leaves; ++q) test_leaf(P.pre_leaf[q]);
+            for (uint32_t q = 0; q < P.n_pre_leaves; ++q) {
+                const uint32_t ref = P.pre_leaf[q]; // wave-uniform
+                const uint32_t cnt = BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u);
+                if (cnt == 1u) { // a lone sphere (the ground): one discriminant, not the pair routine's two
+                    const uint32_t slot = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
+                    float h0, d0;
+                    sphere_delta(lds_spheres[slot], t, h0, d0);
+                    if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, slot, lds_aux, t.tbest, t.best);
+                    if (STATS) st_sphere += 1u;
+                } else {
+                    test_leaf(ref);
+                }
+            }
         } else {
             t.cur = 0; // next sphere of the linear scan
         }
