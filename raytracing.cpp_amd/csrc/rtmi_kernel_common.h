@@ -240,18 +240,18 @@ DEV float draw_pm1(uint32_t u) { return (float)(int32_t)(u ^ 0x80000000u) * 4.65
 DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // The wave's draw service for the shading step.  Every draw is a pure function of (seed, pixel, sample, k), so any
-// lane can evaluate any block of any other lane's stream; once per round each shading lane files one request
-// and the whole wave works them off, 64 blocks per pass:
-//   RQ_UNIT  random_unit_vector (random.number.gen.hpp:21-29; `> 1e-160` on a float is `> 0`).  A per-lane rejection
-//            loop costs the wave its longest run of rejections (6.6 passes for 1.9 attempts per lane at 52 %
-//            acceptance).  Every attempt takes one whole block (it starts at a block boundary and skips the fourth
-//            word), and each pass spreads the lanes still without a vector over all 64 lanes -- pass 1: one attempt
-//            each; pass 2: two attempts for each of the ~27 lanes left; pass 3: ~10 each.  Returns the vector.
-//   RQ_WORD  the raw draw at the current position (the dielectric's reflectance test, material.defs.cc:71): rides
-//            along in the first pass instead of costing the wave a block evaluation of its own at the occupancy of
-//            the dielectric branch.  Returns the bits in .x; the caller advances k if it consumes the draw.
+// lane can evaluate any block of any other lane's stream; once per round each shading lane files one request:
+//   RQ_UNIT  random_unit_vector (random.number.gen.hpp:21-29; `> 1e-160` on a float is `> 0`).  Every attempt takes
+//            one whole block (it starts at a block boundary and skips the fourth word).  A per-lane rejection loop
+//            costs the wave its longest run of rejections (6.6 passes for 1.9 attempts per lane at 52 % acceptance),
+//            so only the first kSelfAttempts attempts are made by the owner (no table, no shuffles: the cheapest
+//            pass there is while most lanes still need one); the ~23 % of lanes still without a vector are then
+//            spread over all 64 lanes -- ~5 attempts each in the next pass, 8 in the one after.  Returns the vector.
+//   RQ_WORD  the raw draw at the current position (the dielectric's reflectance test, material.defs.cc:71): taken in
+//            the owner's first pass.  Returns the bits in .x; the caller advances k if it consumes the draw.
 // `tbl` is 64 bytes of LDS private to the wave.
 enum : uint32_t { RQ_NONE = 0, RQ_UNIT = 1, RQ_WORD = 2 };
+constexpr int kSelfAttempts = 2; // measured on config 3: 0 -> 159.4 ms, 1 -> 153.3, 2 -> 152.5, 3 -> 154.3
 
 // (an LDS-qualified pointer: through a generic one these accesses become flat_* instructions with full waits)
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -259,8 +259,28 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
     V3 out = mk(0.0f, 0.0f, 0.0f);
     if (code == RQ_UNIT) rng.k = (rng.k + 3u) & ~3u; // attempts are block aligned
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const uint32_t word_sel = code == RQ_WORD ? 4u + (rng.k & 3u) : 0u; // bit 2: a word request
     bool pending = code != RQ_NONE;
+#pragma unroll 1
+    for (int self = 0; self < kSelfAttempts; ++self) {
+        if (pending) {
+            Blk tmp;
+            rng4x32(rng.k >> 2, rng.sample, rng.pixel, seed, tmp);
+            if (code == RQ_WORD) { // word (k & 3) of block k >> 2
+                const uint32_t j = rng.k & 3u;
+                out.x = __uint_as_float(j == 0u ? tmp.w0 : (j == 1u ? tmp.w1 : (j == 2u ? tmp.w2 : tmp.w3)));
+                pending = false;
+            } else {
+                const V3 u = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
+                const float l2 = vdot(u, u);
+                rng.k += 4u;
+                if (l2 > 0.0f && l2 <= 1.0f) { // random.number.gen.hpp:25-27
+                    out = u;
+                    pending = false;
+                }
+            }
+        }
+    }
+    // from here on every pending lane is an RQ_UNIT one
     uint64_t todo = ballot(pending);
     while (todo != 0ull) {
         const uint32_t n = (uint32_t)__popcll(todo);
@@ -284,22 +304,16 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
         const bool helper = a < per;
         const uint32_t src = tbl[r];
         const uint32_t pix = (uint32_t)__shfl((int)rng.pixel, (int)src);
-        const uint32_t smp = (uint32_t)__shfl((int)(rng.sample | (word_sel << 16)), (int)src);
+        const uint32_t smp = (uint32_t)__shfl((int)rng.sample, (int)src);
         const uint32_t kb = (uint32_t)__shfl((int)rng.k, (int)src);
         bool ok = false;
         V3 u = mk(0.0f, 0.0f, 0.0f); // the accepted point, not yet normalised
         if (helper) {
             Blk tmp;
-            rng4x32((kb >> 2) + a, smp & 0xffffu, pix, seed, tmp);
-            if (smp & 0x40000u) { // word request: word (k & 3) of block k >> 2
-                const uint32_t j = (smp >> 16) & 3u;
-                u.x = __uint_as_float(j == 0u ? tmp.w0 : (j == 1u ? tmp.w1 : (j == 2u ? tmp.w2 : tmp.w3)));
-                ok = a == 0u;
-            } else {
-                u = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
-                const float l2 = vdot(u, u);
-                ok = l2 > 0.0f && l2 <= 1.0f; // random.number.gen.hpp:25-27
-            }
+            rng4x32((kb >> 2) + a, smp, pix, seed, tmp);
+            u = mk(draw_pm1(tmp.w0), draw_pm1(tmp.w1), draw_pm1(tmp.w2));
+            const float l2 = vdot(u, u);
+            ok = l2 > 0.0f && l2 <= 1.0f;
         }
         const uint64_t okm = ballot(ok);
         // the pending lane takes its first accepted attempt, in attempt order: its attempts sit at bits
@@ -312,7 +326,7 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
         const float ux = __shfl(u.x, (int)from), uy = __shfl(u.y, (int)from), uz = __shfl(u.z, (int)from);
         if (found) {
             out = mk(ux, uy, uz);
-            if (code == RQ_UNIT) rng.k += 4u * (first + 1u);
+            rng.k += 4u * (first + 1u);
             pending = false;
         } else if (pending) {
             rng.k += 4u * per;
