@@ -198,6 +198,18 @@ const char* rtmi_version(void);
 int rtmi_scene_get_stats(rtmi_scene* scene, rtmi_stats* out, int reset);
 /* which kernel rtmi_render_* will launch for this scene: RTMI_ACCEL_BRUTE or RTMI_ACCEL_BVH */
 int rtmi_scene_get_accel(const rtmi_scene* scene, uint32_t* accel_out);
+/* How rtmi_render_* will launch the trace kernel for this scene (what the tuning and the scene's size resolved to). */
+typedef struct rtmi_launch_info {
+    uint32_t struct_size;   /* in: sizeof(rtmi_launch_info) */
+    uint32_t kernel;        /* 1 round-based, 2 queue-scheduled (rtmi_tuning::kernel) */
+    uint32_t block_lanes;   /* lanes per workgroup */
+    uint32_t grid_blocks;   /* persistent workgroups of one launch */
+    uint32_t blocks_per_cu; /* resident workgroups per CU */
+    uint32_t lds_bytes;     /* dynamic LDS per workgroup */
+    uint32_t scene_in_lds;  /* 1: nodes, spheres and materials are staged into LDS; 0: read from HBM through the caches */
+    uint32_t stack_depth;   /* traversal-stack entries per lane */
+} rtmi_launch_info;
+int rtmi_scene_get_launch_info(const rtmi_scene* scene, rtmi_launch_info* out);
 /* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), rmax^2}. */
 int rtmi_scene_get_bvh(const rtmi_scene* scene, rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out,
                        uint32_t* n_slots, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,

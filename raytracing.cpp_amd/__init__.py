@@ -85,6 +85,11 @@ class SceneOptions(C.Structure):
                 ("collect_stats", C.c_uint32), ("reserved", C.c_uint32 * 3), ("tuning", C.POINTER(Tuning))]
 
 
+class LaunchInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("struct_size", "kernel", "block_lanes", "grid_blocks", "blocks_per_cu",
+                                          "lds_bytes", "scene_in_lds", "stack_depth")]
+
+
 class FrameTiming(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("gather_ms", C.c_float), ("kernel_ms", C.c_float * 16)]
 
@@ -126,7 +131,7 @@ assert OBJECT_DTYPE.itemsize == 24 and MATERIAL_DTYPE.itemsize == 20 and BVH_NOD
 # every symbol include/rtmi.h declares
 EXPORTS = ("rtmi_camera_setup", "rtmi_make_world_spheres", "rtmi_scene_create", "rtmi_scene_destroy",
            "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_last_error", "rtmi_version",
-           "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
+           "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_launch_info", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
            "rtmi_bvh_build", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
            "rtmi_frame_render_device", "rtmi_frame_get_timing", "rtmi_frame_rccl_ranks")
 
@@ -163,6 +168,7 @@ def lib():
     L.rtmi_version.restype = C.c_char_p
     L.rtmi_scene_get_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
     L.rtmi_scene_get_accel.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.rtmi_scene_get_launch_info.argtypes = [vp, C.POINTER(LaunchInfo)]
     L.rtmi_scene_get_bvh.argtypes = [vp, vp, C.POINTER(C.c_uint32), vp, C.POINTER(C.c_uint32), vp,
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rtmi_scene_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -282,6 +288,13 @@ class Scene:
         v = C.c_uint32(0)
         _check(lib().rtmi_scene_get_accel(self._h, C.byref(v)))
         return v.value
+
+    def launch_info(self):
+        """rtmi_scene_get_launch_info as a dict."""
+        v = LaunchInfo()
+        v.struct_size = C.sizeof(LaunchInfo)
+        _check(lib().rtmi_scene_get_launch_info(self._h, C.byref(v)))
+        return {n: getattr(v, n) for n, _ in LaunchInfo._fields_ if n != "struct_size"}
 
     def render_rows(self, y0, y1, seed, rgb=True, rgba=True):
         """rtmi_render_rows: host buffers, blocking."""

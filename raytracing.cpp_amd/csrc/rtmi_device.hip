@@ -43,9 +43,116 @@
 
 #include "rtmi_kernel_common.h"
 
+constexpr uint32_t kBlackSample = 0xfffffffeu; // Trav::best of a sample that is finished without tracing (maxdepth == 0)
+
 #ifndef RTMI_WPE
 #define RTMI_WPE 6 // waves per SIMD the register allocation aims at (A/B: 7 = 72 VGPRs + 20 B of scratch, 4 % slower)
 #endif
+
+#ifndef RTMI_ASM_WALK
+#define RTMI_ASM_WALK 1 // 0: the compiler's node step everywhere (the A/B and the fallback for a changed register budget)
+#endif
+static_assert(!RTMI_ASM_WALK || RTMI_WPE <= 6, "the hand-written node loop uses v66-v79 as its node registers");
+
+// The node steps of the walk over an LDS-resident tree as one hand-scheduled loop (gfx950 ISA).  It runs node steps for
+// as long as the vote says "node" and more than `floor` lanes still walk, and returns the two counts of the trip it
+// stopped at (the caller breaks or runs the leaf step).  Same arithmetic, instruction for instruction, as the C++ node
+// step below (which stays the path of the BIG, STATS and RTMI_PROF variants) -- what is gone is the glue the
+// structurizer puts around it: ~72 instructions per trip instead of ~95, and every instruction of this loop costs
+// (10 extra per trip: 3-4 % of the frame).
+//   64-byte node at LDS address nbase + 64 * cur: ctr[2][3] | half[2][3] | child[2] | reserved[2]  (rtmi_bvh_node)
+//   v66-v69 = c0x c0y c0z c1x   v70-v73 = c1y c1z h0x h0y   v74-v77 = h0z h1x h1y h1z   v78,v79 = child 0, 1
+// References are signed (nodes >= 0, leaves < -1, sentinel -1); the stack holds 16-bit entries, one level = `stride`
+// bytes apart; the far child is stored above the top unconditionally and only counts when both boxes are hit.
+// Inline asm is not seen by the hazard recogniser: no VALU-written mask is read by a VALU here (every mask a
+// v_cndmask reads comes out of a scalar instruction), which is the one gfx950 hazard this sequence could meet.
+DEV void walk_nodes_lds(Trav& t, uint32_t nbase, uint32_t stride, int floor, int& n_leaf, int& n_node) {
+    int tmp;
+    uint64_t m_node, m_leaf, saved, hit0, hit1;
+    float x, y, z, tn0;
+    asm volatile(
+        "L_top_%=:\n\t"
+        "v_cmp_le_i32_e64 %[mnode], 0, %[cur]\n\t"
+        "v_cmp_gt_i32_e64 %[mleaf], -1, %[cur]\n\t"
+        "s_bcnt1_i32_b64 %[nnode], %[mnode]\n\t"
+        "s_bcnt1_i32_b64 %[nleaf], %[mleaf]\n\t"
+        "s_add_i32 %[tmp], %[nnode], %[nleaf]\n\t"
+        "s_cmp_le_i32 %[tmp], %[floor]\n\t"
+        "s_cbranch_scc1 L_exit_%=\n\t"
+        "s_cmp_gt_i32 %[nleaf], %[nnode]\n\t"
+        "s_cbranch_scc1 L_exit_%=\n\t"
+        "s_and_saveexec_b64 %[saved], %[mnode]\n\t"
+        "v_lshl_add_u32 %[x], %[cur], 6, %[nbase]\n\t"
+        "ds_read_b128 v[66:69], %[x]\n\t"
+        "ds_read_b128 v[70:73], %[x] offset:16\n\t"
+        "ds_read_b128 v[74:77], %[x] offset:32\n\t"
+        "ds_read_b64 v[78:79], %[x] offset:48\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_fma_f32 v66, v66, %[ix], %[ox]\n\t"      // tc0x
+        "v_fma_f32 v67, v67, %[iy], %[oy]\n\t"      // tc0y
+        "v_fma_f32 v68, v68, %[iz], %[oz]\n\t"      // tc0z
+        "v_fma_f32 v69, v69, %[ix], %[ox]\n\t"      // tc1x
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_fma_f32 v70, v70, %[iy], %[oy]\n\t"      // tc1y
+        "v_fma_f32 v71, v71, %[iz], %[oz]\n\t"      // tc1z
+        "v_fma_f32 v72, v72, |%[ix]|, %[px]\n\t"    // th0x: the pad rides in the FMA of the half extent
+        "v_fma_f32 v73, v73, |%[iy]|, %[py]\n\t"    // th0y
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_fma_f32 v74, v74, |%[iz]|, %[pz]\n\t"    // th0z
+        "v_fma_f32 v75, v75, |%[ix]|, %[px]\n\t"    // th1x
+        "v_fma_f32 v76, v76, |%[iy]|, %[py]\n\t"    // th1y
+        "v_fma_f32 v77, v77, |%[iz]|, %[pz]\n\t"    // th1z
+        "v_sub_f32_e32 %[x], v66, v72\n\t"          // box 0, near: max(x, y, max(z, 1e-4))
+        "v_sub_f32_e32 %[y], v67, v73\n\t"
+        "v_sub_f32_e32 %[z], v68, v74\n\t"
+        "v_max_f32_e32 %[z], 0x38d1b717, %[z]\n\t"
+        "v_max3_f32 %[tn0], %[x], %[y], %[z]\n\t"
+        "v_add_f32_e32 %[x], v66, v72\n\t"          // far: min(x, y, min(z, tbest))
+        "v_add_f32_e32 %[y], v67, v73\n\t"
+        "v_add_f32_e32 %[z], v68, v74\n\t"
+        "v_min_f32_e32 %[z], %[z], %[tbest]\n\t"
+        "v_min3_f32 %[x], %[x], %[y], %[z]\n\t"
+        "v_cmp_le_f32_e64 %[hit0], %[tn0], %[x]\n\t"
+        "v_sub_f32_e32 %[x], v69, v75\n\t"          // box 1
+        "v_sub_f32_e32 %[y], v70, v76\n\t"
+        "v_sub_f32_e32 %[z], v71, v77\n\t"
+        "v_max_f32_e32 %[z], 0x38d1b717, %[z]\n\t"
+        "v_max3_f32 v66, %[x], %[y], %[z]\n\t"      // tn1
+        "v_add_f32_e32 %[x], v69, v75\n\t"
+        "v_add_f32_e32 %[y], v70, v76\n\t"
+        "v_add_f32_e32 %[z], v71, v77\n\t"
+        "v_min_f32_e32 %[z], %[z], %[tbest]\n\t"
+        "v_min3_f32 %[x], %[x], %[y], %[z]\n\t"
+        "v_cmp_le_f32_e64 %[hit1], v66, %[x]\n\t"
+        "v_cmp_lt_f32_e32 vcc, v66, %[tn0]\n\t"     // nearer1
+        "s_orn2_b64 vcc, vcc, %[hit0]\n\t"
+        "s_and_b64 %[mleaf], %[hit1], vcc\n\t"      // take1 = hit1 & (!hit0 | nearer1): the nearer child first
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cndmask_b32_e64 %[x], v79, v78, %[mleaf]\n\t"   // the far child: take1 ? ch0 : ch1
+        "ds_write_b16 %[sp], %[x]\n\t"
+        "v_cndmask_b32_e64 %[cur], v78, v79, %[mleaf]\n\t" // take1 ? ch1 : ch0
+        "s_and_b64 vcc, %[hit0], %[hit1]\n\t"
+        "v_cndmask_b32_e32 %[y], 0, %[stride], vcc\n\t"
+        "v_add_u32_e32 %[sp], %[sp], %[y]\n\t"
+        "s_or_b64 vcc, %[hit0], %[hit1]\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"           // neither box hit: pop
+        "s_cbranch_execz L_nopop_%=\n\t"
+        "v_sub_u32_e32 %[sp], %[sp], %[stride]\n\t"
+        "ds_read_i16 %[cur], %[sp]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "L_nopop_%=:\n\t"
+        "s_mov_b64 exec, %[saved]\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_exit_%=:"
+        : [cur] "+v"(t.cur), [sp] "+v"(t.sp), [nleaf] "=&s"(n_leaf), [nnode] "=&s"(n_node), [tmp] "=&s"(tmp),
+          [mnode] "=&s"(m_node), [mleaf] "=&s"(m_leaf), [saved] "=&s"(saved), [hit0] "=&s"(hit0), [hit1] "=&s"(hit1),
+          [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [tn0] "=&v"(tn0)
+        : [ix] "v"(t.inv.x), [iy] "v"(t.inv.y), [iz] "v"(t.inv.z), [ox] "v"(t.oinv.x), [oy] "v"(t.oinv.y),
+          [oz] "v"(t.oinv.z), [px] "v"(t.pinv.x), [py] "v"(t.pinv.y), [pz] "v"(t.pinv.z), [tbest] "v"(t.tbest),
+          [stride] "v"(stride), [nbase] "s"(nbase), [floor] "s"(floor)
+        : "vcc", "scc", "memory", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
+          "v78", "v79");
+}
 
 // BIG = false: the whole scene is staged into LDS and stack entries are packed into 16 bits (<= 8192 spheres).
 // BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
@@ -60,10 +167,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
     constexpr bool DRAIN = MODE == 2, DEFER = MODE == 1;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
-    // traversal stack: entry 0 of every lane holds a sentinel that ends the walk when it is popped
-    constexpr uint32_t kStackEnd = BIG ? 0xffffffffu : 0xffffu;
-    const uint32_t sp0 = P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT), sp_stride = blockDim.x * (uint32_t)sizeof(StackT);
-    if (ACCEL == RTMI_ACCEL_BVH) *reinterpret_cast<StackT*>(lds_raw + sp0) = (StackT)kStackEnd;
+    // traversal stack: entry 0 of every lane holds a sentinel that ends the walk when it is popped.  References are
+    // signed: nodes >= 0, leaves < -1, the sentinel -1 (16-bit entries are read back sign-extended); t.sp is an LDS address
+    using StackS = typename std::conditional<BIG, int32_t, int16_t>::type;
+    typedef __attribute__((address_space(3))) StackS lds_stack_t;
+    constexpr uint32_t kStackEnd = 0xffffffffu;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8*)lds_raw;
+    const uint32_t sp0 = lds0 + P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT), sp_stride = blockDim.x * (uint32_t)sizeof(StackT);
+    auto stack_at = [](uint32_t addr) -> lds_stack_t* { return (lds_stack_t*)(uintptr_t)addr; };
+    if (ACCEL == RTMI_ACCEL_BVH) *stack_at(sp0) = (StackS)-1;
     uint32_t* lds_att = reinterpret_cast<uint32_t*>(lds_raw + P.lds_att);
     // per-wave pools: work indices and deferred-path slots are taken from the global counters 64 at a time (a single
     // counter word saturates at ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M
@@ -336,8 +448,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
             run_n = 0;
             if (depth_left == 0) {
                 // compute_color(depth == 0) returns 0 at once (core.cc:238-240): the sample is black
-                t.cur = 0xfffffffeu; // marker read by SHADE: finish the sample without tracing
-                t.best = ~0u;
+                t.best = kBlackSample; // marker read by SHADE: finish the sample without tracing
                 phase = PH_SHADE;
             } else {
                 t.o = origin;
@@ -368,11 +479,22 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
             // that never walked start with it), so the two votes come straight from t.cur -- no phase compare, no mask
             // algebra in the loop (every instruction of this loop, scalar ones included, is paid ~15 times per round:
             // ten more s_add per trip cost the frame 4.3 %, ten more v_mov 2.8 %, measured).
-            constexpr uint32_t kLeafLo = BIG ? kLeafBit : 0x8000u;           // leaf references start here ...
-            constexpr uint32_t kLeafSpan = BIG ? 0x7ffffffeu : 0x7fffu;      // ... and end below the markers / the sentinel
             const int trav_floor = max(0, (int)__popcll(ballot(phase == PH_TRAV || phase == PH_SHADE)) - (int)P.wait_thresh);
             for (;;) {
-                const bool at_leaf = (t.cur ^ kLeafLo) < kLeafSpan, at_node = t.cur < kLeafLo;
+#if RTMI_ASM_WALK && !defined(RTMI_PROF)
+                if (!BIG && !STATS) {
+                    int n_leaf, n_node;
+                    walk_nodes_lds(t, lds0, sp_stride, trav_floor, n_leaf, n_node); // nodes start the dynamic LDS segment
+                    if (n_leaf + n_node <= trav_floor) break;
+                    if ((int32_t)t.cur < -1) { // the leaf step won the vote
+                        test_leaf(t.cur);
+                        t.sp -= sp_stride;
+                        t.cur = (uint32_t)(int32_t)*stack_at(t.sp);
+                    }
+                    continue;
+                }
+#endif
+                const bool at_leaf = (int32_t)t.cur < -1, at_node = (int32_t)t.cur >= 0; // (inline constants)
                 const uint64_t m_leaf = ballot(at_leaf);
                 const uint64_t m_node = ballot(at_node);
                 PF_COUNT(pf11);
@@ -432,17 +554,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     const bool take1 = hit1 & (!hit0 | nearer1); // nearer child first (bitwise: no short-circuit branches)
                     // the far child is written above the stack top unconditionally (the stack has one spare level) and only
                     // counts when both boxes are hit: no exec-mask save / restore around the push
-                    *reinterpret_cast<StackT*>(lds_raw + t.sp) = (StackT)(take1 ? ch0 : ch1);
+                    *stack_at(t.sp) = (StackS)(take1 ? ch0 : ch1);
                     t.sp += (hit0 & hit1) ? sp_stride : 0u;
                     t.cur = take1 ? ch1 : ch0; // overwritten by the pop when neither box is hit
                     pop = !(hit0 | hit1);
                 }
                 if (pop) {
                     t.sp -= sp_stride;
-                    t.cur = *reinterpret_cast<const StackT*>(lds_raw + t.sp);
-                    if (t.cur == kStackEnd) phase = PH_SHADE; // the sentinel: stack empty
+                    t.cur = (uint32_t)(int32_t)*stack_at(t.sp);
                 }
             }
+            if (phase == PH_TRAV && t.cur == kStackEnd) phase = PH_SHADE; // popped the sentinel: the walk is over
         } else {
             // the reference's linear closest-hit scan (object.defs.cc:68-81); all lanes of a wave read the same
             // sphere, so every LDS read is a broadcast.
@@ -482,14 +604,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         // unit vectors for every Lambertian / Metallic hit of this round, generated by the whole wave together
         __builtin_amdgcn_s_setprio(0);
         uint32_t rq = RQ_NONE; // Lambertian / Metallic hit: a unit vector; Dielectric hit: one draw
-        if (phase == PH_SHADE && t.cur != 0xfffffffeu && t.best != ~0u) rq = lds_aux[t.best].w != 2u ? RQ_UNIT : RQ_WORD;
+        if (phase == PH_SHADE && t.best < kBlackSample) rq = lds_aux[t.best].w != 2u ? RQ_UNIT : RQ_WORD;
         PF_MARK(pf8);
         const V3 unit_vec = coop_draws(rq, rng, P.seed, rank_tbl);
         PF_MARK(pf5);
         if (phase == PH_SHADE) {
             bool ended = false;
             V3 color = mk(0.0f, 0.0f, 0.0f);
-            if (t.cur == 0xfffffffeu) {
+            if (t.best == kBlackSample) {
                 ended = true; // maxdepth == 0: black sample
             } else if (t.best != ~0u) {
                 // IntersectionRecord for the winning sphere, object.defs.cc:62-65 and :11-18
@@ -817,6 +939,7 @@ struct rtmi_scene {
     // scene, 3.5 % better than 56 on the HBM-resident 100k-sphere scene; 62 costs that scene 23 %)
     uint32_t wait_thresh = 52;
     uint32_t lds_att = 0, lds_pool = 0;
+    uint32_t n_cus = 0;
     uint32_t drain_wait_thresh = 56;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     uint32_t pre_leaf_dev[4] = {}; // leaves peeled off the top of the tree, tested at segment set-up
@@ -1274,8 +1397,10 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     {
         // device copy of the nodes: LDS-resident scenes get their references in the 16-bit stack-entry form
         std::vector<rtmi_bvh_node> dn = s->bvh.nodes;
+        // (leaf references are stored sign-extended: as 32-bit integers nodes are >= 0, leaves < -1 and the stack's
+        // sentinel -1 in both layouts, so the walk's votes are two compares against inline constants)
         auto pack16 = [](uint32_t ref) {
-            return (ref & kLeafBit) ? (0x8000u | ((((ref >> 24) & 0x7fu) - 1u) << 13) | (ref & 0x1fffu)) : ref;
+            return (ref & kLeafBit) ? (0xffff8000u | ((((ref >> 24) & 0x7fu) - 1u) << 13) | (ref & 0x1fffu)) : ref;
         };
         s->root_ref_dev = s->bvh.root_ref;
         if (!s->big && s->accel == RTMI_ACCEL_BVH && n_objects > 0) {
@@ -1375,7 +1500,8 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     if (tune.drain_wait_thresh) s->drain_wait_thresh = std::min(64u, tune.drain_wait_thresh);
     if (tune.sample_buf_mb) s->sample_buf_cap_bytes = (size_t)tune.sample_buf_mb << 20;
     s->top_down = tune.top_down != 0;
-    s->grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    s->n_cus = (uint32_t)prop.multiProcessorCount;
+    s->grid = s->n_cus * (uint32_t)per_cu;
 
     // ---- queue-scheduled kernel: slot pool, rings and control words behind the staged scene and the stacks ------------
     s->wf_enabled = s->accel == RTMI_ACCEL_BVH && n_objects > 0 && tune.kernel == 2u; // 0 / 1: round-based kernel
@@ -1546,6 +1672,22 @@ extern "C" int rtmi_scene_get_accel(const rtmi_scene* s, uint32_t* accel_out) {
         return RTMI_ERR_BAD_ARG;
     }
     *accel_out = s->accel;
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_get_launch_info(const rtmi_scene* s, rtmi_launch_info* out) {
+    if (!s || !out || out->struct_size != sizeof(rtmi_launch_info)) {
+        set_error("rtmi_scene_get_launch_info: null argument or struct_size mismatch");
+        return RTMI_ERR_BAD_ARG;
+    }
+    const bool wf = s->wf_enabled && s->accel == RTMI_ACCEL_BVH;
+    out->kernel = wf ? 2u : 1u;
+    out->block_lanes = wf ? s->wf_block : s->block;
+    out->grid_blocks = wf ? s->wf_grid : s->grid;
+    out->blocks_per_cu = s->n_cus ? out->grid_blocks / s->n_cus : 0u;
+    out->lds_bytes = wf ? s->wf_lds_bytes : s->lds_bytes;
+    out->scene_in_lds = s->big ? 0u : 1u;
+    out->stack_depth = s->stack_depth;
     return RTMI_OK;
 }
 

@@ -146,6 +146,24 @@ def test_hbm_resident_scene_variant(pkg, ob, rtow, gpu):
         assert np.array_equal(rgba, want8)
 
 
+def test_launch_info_reports_what_the_tuning_resolved_to(pkg, rtow, gpu):
+    """rtmi_scene_get_launch_info: the RTOW scene is staged into LDS with two 768-lane workgroups per CU (6 waves per
+    SIMD); forcing the HBM layout, another block size or the queue-scheduled kernel shows up in the report."""
+    cam = pkg.camera_setup(pkg.camera_params(image_width=64, samples_per_pixel=2, max_depth=8))
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH) as s:
+        li = s.launch_info()
+    assert li["kernel"] == 1 and li["block_lanes"] == 768 and li["blocks_per_cu"] == 2 and li["scene_in_lds"] == 1
+    assert li["grid_blocks"] % 2 == 0 and 0 < li["lds_bytes"] <= 80 * 1024 and li["stack_depth"] >= 3
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(force_hbm_scene=1, block_lanes=512)) as s:
+        li2 = s.launch_info()
+    assert li2["scene_in_lds"] == 0 and li2["block_lanes"] == 512 and li2["lds_bytes"] < li["lds_bytes"]
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(kernel=2)) as s:
+        li3 = s.launch_info()
+    assert li3["kernel"] == 2 and li3["block_lanes"] == 1024
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(blocks_per_cu=1)) as s:
+        assert s.launch_info()["blocks_per_cu"] == 1
+
+
 def test_scheduling_knobs_do_not_change_the_image(pkg, ob, rtow, gpu):
     """Sample-chunk work items, the deferred-path queue (also when it overflows), launch geometry and the traversal
     exit threshold are scheduling decisions: every combination yields the oracle's frame bit for bit."""

@@ -48,6 +48,8 @@ for rnd in range(2):
                 objs, mats = pkg.make_world_spheres(12345)
             cam = pkg.camera_setup(pkg.camera_params(image_width=w, samples_per_pixel=spp, max_depth=50))
         with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=tuning or None) as sc:
+            if rnd == 0:
+                print(f"      {name}: {sc.launch_info()}")
             ms = []
             for _ in range(2):
                 rgb, _ = sc.render_rows(0, cam.img_height, 7, rgba=False)
