@@ -279,6 +279,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
     auto test_leaf = [&](uint32_t ref) {
         const uint32_t first = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
         const uint32_t cnt = BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u);
+        const Recip ra = recip_for(t.a); // shared by every root of this leaf step
         auto pair = [&](uint32_t q) {
             const bool two = q + 1u < cnt;
             const uint4 r0 = lds_spheres[first + q];
@@ -286,8 +287,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
             float h0, h1, d0, d1;
             sphere_delta(r0, t, h0, d0);
             sphere_delta(r1, t, h1, d1);
-            if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, first + q, lds_aux, t.tbest, t.best);
-            if (two & (d1 >= 0.0f)) sphere_root_bvh(h1, d1, t, first + q + 1u, lds_aux, t.tbest, t.best);
+            if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, ra, first + q, lds_aux, t.tbest, t.best);
+            if (two & (d1 >= 0.0f)) sphere_root_bvh(h1, d1, t, ra, first + q + 1u, lds_aux, t.tbest, t.best);
         };
         pair(0u);
         if (cnt > 2u) {
@@ -329,7 +330,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     const uint32_t slot = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
                     float h0, d0;
                     sphere_delta(lds_spheres[slot], t, h0, d0);
-                    if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, slot, lds_aux, t.tbest, t.best);
+                    if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, recip_for(t.a), slot, lds_aux, t.tbest, t.best);
                     if (STATS) st_sphere += 1u;
                 } else {
                     test_leaf(ref);
@@ -345,6 +346,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         PF_MARK(pf9);
         PF_COUNT(pf10);
         // ---- FETCH: one wave-aggregated atomic hands out consecutive indices of the 8x8-tiled pixel space -----
+        ISA_MARK("fetch");
         while (phase == PH_FETCH) {
             const uint64_t need = ballot(true);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -416,6 +418,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         PF_LANES(pl5, ballot(phase == PH_GEN));
 
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
+        ISA_MARK("gen");
         if (!DRAIN && phase == PH_GEN) {
             const uint32_t blk = fdiv(ply, P.div_block_rows);
             const uint32_t gy = P.y_first + blk * P.block_stride * P.block_rows + (ply - blk * P.block_rows);
@@ -458,6 +461,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         }
         // every new segment of this round -- primary rays, scattered rays, resumed paths -- is set up here, once
         PF_MARK(pf1);
+        ISA_MARK("begin");
         if (phase == PH_BEGIN) {
             PF_LANES(pl6, ballot(true));
             begin_segment(t.o, t.d);
@@ -466,6 +470,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
 
         // waves in the traversal loop issue ahead of waves that shade, draw or fetch: the loop is where the lanes are
         // (A/B on MI355X: +1.3 %; the other way round -0.4 %)
+        ISA_MARK("walk");
         __builtin_amdgcn_s_setprio(1);
         PF_MARK(pf6);
         // ---- TRAVERSE ---------------------------------------------------------------------------------------------
@@ -602,11 +607,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         PF_LANES(pl7, ballot(phase == PH_DONE));
         // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
         // unit vectors for every Lambertian / Metallic hit of this round, generated by the whole wave together
+        ISA_MARK("request");
         __builtin_amdgcn_s_setprio(0);
         uint32_t rq = RQ_NONE; // Lambertian / Metallic hit: a unit vector; Dielectric hit: one draw
         if (phase == PH_SHADE && t.best < kBlackSample) rq = lds_aux[t.best].w != 2u ? RQ_UNIT : RQ_WORD;
         PF_MARK(pf8);
+        ISA_MARK("draws");
         const V3 unit_vec = coop_draws(rq, rng, P.seed, rank_tbl);
+        ISA_MARK("shade");
         PF_MARK(pf5);
         if (phase == PH_SHADE) {
             bool ended = false;
@@ -625,6 +633,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                 const V3 N = front ? outward : vneg(outward);
                 const uint32_t mh = araw.y;
                 const uint4 m0 = lds_mats[mh]; // {albedo, fuzz} or {refraction index, ...}
+                ISA_MARK("shade-material");
                 const uint32_t kind = araw.w;
                 V3 sd = mk(0.0f, 0.0f, 0.0f);
                 bool scattered = true;
@@ -663,6 +672,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     }
                     sd = reflect_it ? vreflect(unit_dir, N) : vrefract(unit_dir, N, eta);
                 }
+                ISA_MARK("shade-continue");
                 if (!scattered) {
                     ended = true; // absorbed: compute_color returns 0 (core.cc:251)
                 } else {
@@ -723,6 +733,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     }
                 }
             } else {
+                ISA_MARK("shade-miss");
                 // miss: sky gradient (core.cc:254-256), then the attenuations innermost-first (core.cc:247-248)
                 const V3 unit_dir = vnormalize(t.d);
                 const float tt = 0.5f * (unit_dir.y + 1.0f);
@@ -751,6 +762,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                 }
                 ended = true;
             }
+            ISA_MARK("shade-ended");
             if (ended) {
                 // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
                 if (P.sample_buf) {
@@ -797,6 +809,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
             }
         }
         PF_MARK(pf3);
+        ISA_MARK("loop-end");
     }
 
     if (DEFER && P.defer_buf && lane == 0u) { // reserved but unused slots become empty records (depth 0)

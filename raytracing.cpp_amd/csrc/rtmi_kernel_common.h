@@ -139,6 +139,14 @@ DEV NodeFields unpack_node64(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
 #define PF_LANES(acc, mask) do { } while (0)
 #endif
 
+// Static code map (diagnostic build only, -DRTMI_MARKS): comment lines in the ISA at the phase boundaries, so that
+// tools/isa_phases.py can count the instructions of each phase.
+#ifdef RTMI_MARKS
+#define ISA_MARK(name) asm volatile("; @@" name)
+#else
+#define ISA_MARK(name) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // vec3 with glm's published semantics (glm is an un-vendored dependency of the reference)
 // ---------------------------------------------------------------------------------------------------------
@@ -378,12 +386,45 @@ DEV void sphere_root(float h, float delta, const Trav& t, uint32_t slot, float& 
     }
 }
 
+// Correctly rounded fp32 division the way the compiler expands `/` for this target (v_div_scale x 2, v_rcp, four FMAs,
+// v_mul, v_div_fmas, v_div_fixup), minus the three operations that do nothing while the operands are in range: with
+// the denominator in [2^-40, 2^40] and a quotient that matters (|q| in [1e-4, 2^40)) v_div_scale passes both operands
+// through unscaled, v_div_fmas is a plain FMA and v_div_fixup returns its input, so the sequence below IS that expansion,
+// bit for bit -- and the reciprocal (v_rcp + two FMAs) is shared by every division by the same denominator.
+struct Recip {
+    float den, r; // r = rcp(den) after one Newton step, as in the expansion
+    bool in_range;
+};
+DEV Recip recip_for(float den) {
+    Recip q;
+    q.den = den;
+    const float r0 = __builtin_amdgcn_rcpf(den);
+    const float e = __builtin_fmaf(-den, r0, 1.0f);
+    q.r = __builtin_fmaf(e, r0, r0);
+    q.in_range = den >= 0x1p-40f && den <= 0x1p40f; // (false for NaN)
+    return q;
+}
+DEV float div_in_range(float num, const Recip& d) {
+    const float q0 = num * d.r;
+    const float rem0 = __builtin_fmaf(-d.den, q0, num);
+    const float q1 = __builtin_fmaf(rem0, d.r, q0);
+    const float rem1 = __builtin_fmaf(-d.den, q1, num);
+    return __builtin_fmaf(rem1, d.r, q1);
+}
+
 // Root + acceptance for the BVH walk, where leaves are not visited in insertion order: a strictly closer root wins; an
 // exactly equal one wins only if its object was inserted earlier (what the reference's in-order scan with `<` yields).
-DEV void sphere_root_bvh(float h, float delta, const Trav& t, uint32_t slot, const uint4* aux, float& tbest, uint32_t& best) {
+// `ra` = recip_for(t.a), computed once per leaf step.  A root at or below the 1e-4 cut is only compared, never kept: an
+// imprecise tiny quotient (numerator below the range the expansion would rescale) takes the same branches as the exact one.
+DEV void sphere_root_bvh(float h, float delta, const Trav& t, const Recip& ra, uint32_t slot, const uint4* aux, float& tbest,
+                         uint32_t& best) {
     const float sqrtd = __builtin_sqrtf(delta);
-    float root = (h - sqrtd) / t.a;
-    if (!(root > 0.0001f)) root = (h + sqrtd) / t.a;
+    float root = div_in_range(h - sqrtd, ra);
+    if (!(root > 0.0001f)) root = div_in_range(h + sqrtd, ra);
+    if (!(ra.in_range && __builtin_fabsf(root) < 0x1p40f)) { // out of range (or NaN): the full expansion
+        root = (h - sqrtd) / t.a;
+        if (!(root > 0.0001f)) root = (h + sqrtd) / t.a;
+    }
     if (root > 0.0001f) {
         if (root < tbest) {
             tbest = root;
