@@ -628,7 +628,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                 const V3 C = mk(__uint_as_float(sraw.x), __uint_as_float(sraw.y), __uint_as_float(sraw.z));
                 const float R = __uint_as_float(araw.z);
                 const V3 p = vadd(t.o, vscale(t.d, t.tbest)); // Ray::point_at_param, ray.hpp:9
-                const V3 outward = vdivs(vsub(p, C), R);
+                const V3 pc = vsub(p, C);
+                const V3 outward = vdivs_shared(pc, R, comps_in_range(pc)); // (p - C) / R, object.defs.cc:13
                 const bool front = vdot(t.d, outward) < 0.0f;
                 const V3 N = front ? outward : vneg(outward);
                 const uint32_t mh = araw.y;

@@ -174,6 +174,46 @@ DEV V3 vrefract(V3 I, V3 N, float eta) {
 }
 DEV V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 
+// Correctly rounded fp32 division the way the compiler expands `/` for this target (v_div_scale x 2, v_rcp, four FMAs,
+// v_mul, v_div_fmas, v_div_fixup), minus the three operations that do nothing while the operands are in range: with
+// the denominator in [2^-40, 2^40] and a quotient that matters (|q| in [1e-4, 2^40)) v_div_scale passes both operands
+// through unscaled, v_div_fmas is a plain FMA and v_div_fixup returns its input, so the sequence below IS that expansion,
+// bit for bit -- and the reciprocal (v_rcp + two FMAs) is shared by every division by the same denominator.
+struct Recip {
+    float den, r; // r = rcp(den) after one Newton step, as in the expansion
+    bool in_range;
+};
+DEV Recip recip_for(float den) {
+    Recip q;
+    q.den = den;
+    const float r0 = __builtin_amdgcn_rcpf(den);
+    const float e = __builtin_fmaf(-den, r0, 1.0f);
+    q.r = __builtin_fmaf(e, r0, r0);
+    q.in_range = __builtin_fabsf(den) >= 0x1p-40f && __builtin_fabsf(den) <= 0x1p40f; // (false for NaN)
+    return q;
+}
+DEV float div_in_range(float num, const Recip& d) {
+    const float q0 = num * d.r;
+    const float rem0 = __builtin_fmaf(-d.den, q0, num);
+    const float q1 = __builtin_fmaf(rem0, d.r, q0);
+    const float rem1 = __builtin_fmaf(-d.den, q1, num);
+    return __builtin_fmaf(rem1, d.r, q1);
+}
+
+// a / s, component by component (glm's vec3 / scalar), on one shared reciprocal.  In range means: |s| in [2^-40, 2^40]
+// and every component of `a` is +0 or at least 2^-60 in magnitude (a -0 would come out as +0, a tinier one would be
+// rescaled by the expansion); the caller vouches for `comps_ok` or passes the test below (which sends zeros the slow way too).
+DEV bool comps_in_range(V3 a) {
+    return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z)) >= 0x1p-60f;
+}
+DEV V3 vdivs_shared(V3 a, float s, bool comps_ok) {
+    const Recip rs = recip_for(s);
+    V3 q = mk(div_in_range(a.x, rs), div_in_range(a.y, rs), div_in_range(a.z, rs));
+    if (!(rs.in_range && comps_ok)) q = vdivs(a, s); // the full expansion (rare: the wave skips it)
+    return q;
+}
+
+
 // ---------------------------------------------------------------------------------------------------------
 // counter RNG: draw #k of (seed, pixel, sample) = word (k & 3) of block k >> 2 of that stream (rng4x32 below);
 // random_double() = u32 * 2^-32.  The affine maps of random.number.gen.hpp are exact in double for a 32-bit
@@ -342,7 +382,8 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
         todo = ballot(pending);
     }
     // p / sqrt(dot(p, p)) once, on the owner's lane: the IEEE square root and divisions are not paid per attempt
-    if (code == RQ_UNIT) out = vdivs(out, __builtin_sqrtf(vdot(out, out)));
+    // (components are multiples of 2^-31 in (-1, 1), +0 included, and 2^-31 <= sqrt <= 1: always in range)
+    if (code == RQ_UNIT) out = vdivs_shared(out, __builtin_sqrtf(vdot(out, out)), true);
     return out;
 }
 
@@ -384,32 +425,6 @@ DEV void sphere_root(float h, float delta, const Trav& t, uint32_t slot, float& 
         tbest = root;
         best = slot;
     }
-}
-
-// Correctly rounded fp32 division the way the compiler expands `/` for this target (v_div_scale x 2, v_rcp, four FMAs,
-// v_mul, v_div_fmas, v_div_fixup), minus the three operations that do nothing while the operands are in range: with
-// the denominator in [2^-40, 2^40] and a quotient that matters (|q| in [1e-4, 2^40)) v_div_scale passes both operands
-// through unscaled, v_div_fmas is a plain FMA and v_div_fixup returns its input, so the sequence below IS that expansion,
-// bit for bit -- and the reciprocal (v_rcp + two FMAs) is shared by every division by the same denominator.
-struct Recip {
-    float den, r; // r = rcp(den) after one Newton step, as in the expansion
-    bool in_range;
-};
-DEV Recip recip_for(float den) {
-    Recip q;
-    q.den = den;
-    const float r0 = __builtin_amdgcn_rcpf(den);
-    const float e = __builtin_fmaf(-den, r0, 1.0f);
-    q.r = __builtin_fmaf(e, r0, r0);
-    q.in_range = den >= 0x1p-40f && den <= 0x1p40f; // (false for NaN)
-    return q;
-}
-DEV float div_in_range(float num, const Recip& d) {
-    const float q0 = num * d.r;
-    const float rem0 = __builtin_fmaf(-d.den, q0, num);
-    const float q1 = __builtin_fmaf(rem0, d.r, q0);
-    const float rem1 = __builtin_fmaf(-d.den, q1, num);
-    return __builtin_fmaf(rem1, d.r, q1);
 }
 
 // Root + acceptance for the BVH walk, where leaves are not visited in insertion order: a strictly closer root wins; an
