@@ -659,7 +659,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     const float r1 = front ? __uint_as_float(m0.z) : __uint_as_float(m0.w);
                     const V3 unit_dir = vnormalize(t.d);
                     const float cos_theta = fminf(vdot(vneg(unit_dir), N), 1.0f);
-                    const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+                    const float sin_theta = sqrt_shared(1.0f - cos_theta * cos_theta);
                     bool reflect_it = (eta * sin_theta) > 1.0f;
                     if (!reflect_it) { // short-circuit ||: the draw happens only when refraction is possible
                         // powf(x, 5): x^5 through double is the correctly rounded value except for ties

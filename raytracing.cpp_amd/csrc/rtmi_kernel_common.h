@@ -164,12 +164,13 @@ DEV float vdot(V3 a, V3 b) { // glm::dot: t = a*b; t.x + t.y + t.z
     const float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
     return (tx + ty) + tz;
 }
-DEV V3 vnormalize(V3 v) { return vscale(v, 1.0f / __builtin_sqrtf(vdot(v, v))); } // v * inversesqrt(dot(v,v))
+DEV float sqrt_shared(float x);
+DEV V3 vnormalize(V3 v) { return vscale(v, 1.0f / sqrt_shared(vdot(v, v))); } // v * inversesqrt(dot(v,v))
 DEV V3 vreflect(V3 I, V3 N) { return vsub(I, vscale(vscale(N, vdot(N, I)), 2.0f)); }
 DEV V3 vrefract(V3 I, V3 N, float eta) {
     const float d = vdot(N, I);
     const float k = 1.0f - eta * eta * (1.0f - d * d);
-    if (k >= 0.0f) return vsub(vscale(I, eta), vscale(N, eta * d + __builtin_sqrtf(k)));
+    if (k >= 0.0f) return vsub(vscale(I, eta), vscale(N, eta * d + sqrt_shared(k)));
     return mk(0.0f, 0.0f, 0.0f);
 }
 DEV V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
@@ -198,6 +199,26 @@ DEV float div_in_range(float num, const Recip& d) {
     const float q1 = __builtin_fmaf(rem0, d.r, q0);
     const float rem1 = __builtin_fmaf(-d.den, q1, num);
     return __builtin_fmaf(rem1, d.r, q1);
+}
+
+// Correctly rounded fp32 square root, likewise: the compiler's expansion of sqrtf is v_sqrt_f32 plus two residual tests
+// that move the estimate one ulp down or up; around that it rescales arguments below 2^-96 and passes 0 / inf through.
+// For 2^-90 <= x <= 2^90 those wrappers do nothing and the core below is the whole expansion.
+DEV float sqrt_core(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float q = r_dn <= 0.0f ? s_dn : s;
+    q = r_up > 0.0f ? s_up : q;
+    return q;
+}
+DEV float sqrt_shared(float x) {
+    float q = sqrt_core(x);
+    if (!(x >= 0x1p-90f && x <= 0x1p90f)) { // (also NaN, 0, negative: the full expansion)
+        asm volatile("" : "+v"(x)); // a real branch: left alone the compiler evaluates both square roots and selects
+        q = __builtin_sqrtf(x);
+    }
+    return q;
 }
 
 // a / s, component by component (glm's vec3 / scalar), on one shared reciprocal.  In range means: |s| in [2^-40, 2^40]
@@ -383,7 +404,8 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
     }
     // p / sqrt(dot(p, p)) once, on the owner's lane: the IEEE square root and divisions are not paid per attempt
     // (components are multiples of 2^-31 in (-1, 1), +0 included, and 2^-31 <= sqrt <= 1: always in range)
-    if (code == RQ_UNIT) out = vdivs_shared(out, __builtin_sqrtf(vdot(out, out)), true);
+    // (and 2^-62 <= dot <= 1 for the square root)
+    if (code == RQ_UNIT) out = vdivs_shared(out, sqrt_core(vdot(out, out)), true);
     return out;
 }
 
@@ -433,7 +455,7 @@ DEV void sphere_root(float h, float delta, const Trav& t, uint32_t slot, float& 
 // imprecise tiny quotient (numerator below the range the expansion would rescale) takes the same branches as the exact one.
 DEV void sphere_root_bvh(float h, float delta, const Trav& t, const Recip& ra, uint32_t slot, const uint4* aux, float& tbest,
                          uint32_t& best) {
-    const float sqrtd = __builtin_sqrtf(delta);
+    const float sqrtd = sqrt_shared(delta);
     float root = div_in_range(h - sqrtd, ra);
     if (!(root > 0.0001f)) root = div_in_range(h + sqrtd, ra);
     if (!(ra.in_range && __builtin_fabsf(root) < 0x1p40f)) { // out of range (or NaN): the full expansion
