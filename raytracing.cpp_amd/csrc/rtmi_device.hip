@@ -619,6 +619,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         if (phase == PH_SHADE) {
             bool ended = false;
             V3 color = mk(0.0f, 0.0f, 0.0f);
+            // unit_vector(ray.direction) of the Dielectric scatter (material.defs.cc:60) and of the sky gradient
+            // (core.cc:254): one evaluation for the lanes of both branches instead of one per branch (-1.6 %; folding the
+            // Metallic branch's normalize(reflect(d, N)) into it as well gained nothing more)
+            V3 unit_dir = mk(0.0f, 0.0f, 0.0f);
+            if (rq == RQ_WORD || t.best == ~0u) unit_dir = vnormalize(t.d);
             if (t.best == kBlackSample) {
                 ended = true; // maxdepth == 0: black sample
             } else if (t.best != ~0u) {
@@ -657,7 +662,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     // material and the face only: both pairs are computed once on the host with the same fp32 operations
                     const float eta = front ? __uint_as_float(m0.y) : __uint_as_float(m0.x);
                     const float r1 = front ? __uint_as_float(m0.z) : __uint_as_float(m0.w);
-                    const V3 unit_dir = vnormalize(t.d);
                     const float cos_theta = fminf(vdot(vneg(unit_dir), N), 1.0f);
                     const float sin_theta = sqrt_shared(1.0f - cos_theta * cos_theta);
                     bool reflect_it = (eta * sin_theta) > 1.0f;
@@ -736,7 +740,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
             } else {
                 ISA_MARK("shade-miss");
                 // miss: sky gradient (core.cc:254-256), then the attenuations innermost-first (core.cc:247-248)
-                const V3 unit_dir = vnormalize(t.d);
                 const float tt = 0.5f * (unit_dir.y + 1.0f);
                 color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
                 color = att_apply(color, run_h, run_n);
