@@ -220,6 +220,47 @@ def test_random_scenes_and_cameras(pkg, ob, gpu):
             assert np.array_equal(rgba, want8), (case, name)
 
 
+def test_operands_outside_the_range_of_the_division_and_square_root_cores(pkg, ob, gpu):
+    """The kernel divides and takes square roots through the in-range cores of the compiler's expansions and falls back
+    to the full expansions outside [2^-40, 2^40] (denominators), 2^-60 (numerators) and [2^-90, 2^90] (radicands).
+    Worlds scaled by 2^-25 ... 2^+25 put dot(d, d), the discriminants and the radii on both sides of those limits; a
+    sphere whose centre coordinates are 2^24 has hit points whose offset from the centre is exactly zero in a component
+    (the spacing of fp32 there is 2).  Same frames as the oracle, which divides with `/` and calls sqrtf."""
+    rng = np.random.default_rng(77)
+    base = [((0.0, -1000.0, 0.0), 1000.0, (0, (0.5, 0.5, 0.5, 0.0)))]
+    for _ in range(24):
+        k = int(rng.choice([0, 0, 1, 2]))
+        prm = ((*rng.uniform(0.1, 0.9, 3), 0.0) if k == 0 else (*rng.uniform(0.5, 1.0, 3), float(rng.uniform(0.0, 0.4))) if k == 1
+               else (1.5, 0.0, 0.0, 0.0))
+        r = float(rng.choice([0.2, 0.5, 1.0]))
+        base.append(((float(rng.uniform(-4, 4)), r, float(rng.uniform(-4, 4))), r, (k, prm)))
+    for log2_scale in (-25, -17, 0, 17, 25):
+        sc = 2.0 ** log2_scale
+        objs, mats = arrays([((c[0] * sc, c[1] * sc, c[2] * sc), r * sc, m) for c, r, m in base])
+        kw = dict(image_width=48, samples_per_pixel=4, max_depth=12, vertical_fov=40.0, defocus_angle=0.6,
+                  focus_distance=10.0 * sc, lookfrom=(9.0 * sc, 2.0 * sc, 3.0 * sc), lookat=(0.0, 0.5 * sc, 0.0))
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        want, want8 = ob.render_rect_counter(ocam, objs, mats, 5, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
+        assert np.isfinite(want).all() and want.max() > 0.0, log2_scale
+        for accel, name in _both(pkg):
+            with pkg.Scene(cam, objs, mats, accel=accel) as s:
+                rgb, rgba = s.render_rows(0, cam.img_height, 5)
+            _assert_frames_equal(rgb, want)
+            assert np.array_equal(rgba, want8), (log2_scale, name)
+    big = float(2 ** 24)
+    objs, mats = arrays([((big, big, big), 1.0, (0, (0.7, 0.3, 0.3, 0.0))), ((big + 4.0, big, big), 2.0, (1, (0.8, 0.8, 0.8, 0.1))),
+                         ((big, big - 1002.0, big), 1000.0, (0, (0.5, 0.5, 0.5, 0.0)))])
+    kw = dict(image_width=40, samples_per_pixel=8, max_depth=8, vertical_fov=30.0, defocus_angle=0.0, focus_distance=10.0,
+              lookfrom=(big + 2.0, big + 2.0, big + 16.0), lookat=(big + 2.0, big, big))
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    want, want8 = ob.render_rect_counter(ocam, objs, mats, 6, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
+    for accel, name in _both(pkg):
+        with pkg.Scene(cam, objs, mats, accel=accel) as s:
+            rgb, rgba = s.render_rows(0, cam.img_height, 6)
+        _assert_frames_equal(rgb, want)
+        assert np.array_equal(rgba, want8), name
+
+
 def test_degenerate_scenes(pkg, ob, gpu):
     kw = dict(image_width=40, samples_per_pixel=2, max_depth=5)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
