@@ -504,7 +504,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                 const uint64_t m_node = ballot(at_node);
                 PF_COUNT(pf11);
 #ifdef RTMI_PROF
-                if (__popcll(m_leaf) > __popcll(m_node)) { PF_COUNT(pl0); PF_LANES(pl1, m_leaf); } else { PF_LANES(pl2, m_node); }
+                if (__popcll(m_leaf) > __popcll(m_node)) { PF_COUNT(pl0); PF_LANES(pl1, m_leaf); PF_LANES(pf7, m_node); } else { PF_LANES(pl2, m_node); PF_LANES(pf4, m_leaf); }
 #endif
                 int n_leaf = (int)__popcll(m_leaf), n_node = (int)__popcll(m_node);
                 // keep the counts 32-bit scalars: left alone the compiler compares the 64-bit popcounts, for which

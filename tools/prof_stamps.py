@@ -28,6 +28,8 @@ with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
 names = ["fetch", "gen", "traverse", "shade", "-", "coop-unit", "begin-seg", "-", "pre-coop", "loop-glue", "#rounds", "#trav-iters"]
 for label, base in (("primary", 0), ("drain", 32)):
     v = [int(x) for x in out[base + 8:base + 20]]
+    idle_leaf, idle_node = v[4], v[7]  # lanes waiting at a leaf during node trips / at a node during leaf trips
+    v[4] = v[7] = 0
     tot = sum(v[:10])
     if tot == 0:
         continue
@@ -38,5 +40,6 @@ for label, base in (("primary", 0), ("drain", 32)):
     rounds, iters = v[10], v[11]
     leaf_it, node_it = L[0], iters - L[0]
     print(f"  node iters/round {node_it/rounds:.2f} mean lanes {L[2]/max(1,node_it):.1f};  leaf iters/round {leaf_it/rounds:.2f} mean lanes {L[1]/max(1,leaf_it):.1f}")
+    print(f"  lanes parked at a leaf per node trip {idle_leaf/max(1,node_it):.1f}; lanes parked at a node per leaf trip {idle_node/max(1,leaf_it):.1f}")
     print(f"  per round: shade lanes {L[3]/rounds:.1f} (miss {L[4]/rounds:.1f}), gen lanes {L[5]/rounds:.1f}, begin lanes {L[6]/rounds:.1f}, done lanes {L[7]/rounds:.1f}")
     print(f"  trav iters per round: {v[11]/max(1,v[10]):.2f}; cycles per trav iter: {v[2]/max(1,v[11]):.1f}; cycles per round: {tot/max(1,v[10]):.1f}")
