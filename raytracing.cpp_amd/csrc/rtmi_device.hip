@@ -17,8 +17,12 @@
 //    chain A1*(A2*(...*sky)) of the recursive compute_color is replayed innermost-first at path end from run-length
 //    encoded material handles kept in LDS, so the colour is bit-identical to the recursion.
 //  * traversal: per iteration the wave votes between a node step and a leaf step; it leaves the loop as soon as
-//    enough lanes wait for shading (ballot/popcount), shades them, refills them and re-enters traversal.
-//  * rejection sampling of random_unit_vector is done by the whole wave together (coop_draws).
+//    enough lanes wait for shading (ballot/popcount), shades them, refills them and re-enters traversal.  The node
+//    steps of LDS-resident trees are one hand-scheduled gfx950 loop (walk_nodes_lds); the C++ node step beside it
+//    serves the HBM-resident, statistics and stamp variants.
+//  * random_unit_vector: the owner lane makes its first two attempts, the wave shares the retries (coop_draws).
+//  * the reference's fp32 divisions and square roots run as the in-range cores of the compiler's own expansions
+//    (bit-identical, a third of the instructions), the full expansions behind a branch for operands out of range.
 //  * paths that turn out to bounce inside an opaque sphere are deferred to a compacted queue and finished by a
 //    second launch (DRAIN variant) whose lanes all walk such paths -- for launches long enough to pay for it.
 //  * scene (BVH nodes, spheres, materials) staged once per workgroup into LDS with coalesced 16-byte loads; the
