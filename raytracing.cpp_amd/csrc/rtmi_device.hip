@@ -167,8 +167,9 @@ template <int ACCEL, bool STATS, bool BIG, int MODE>
 // 6 waves per SIMD (<= 80 VGPRs): two workgroups of 768 lanes per CU; that occupancy is worth +17 % over 4 waves per
 // SIMD (measured), and one register more would silently halve it -- hence the explicit bound
 __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
-    // MODE 0: plain launch; 1: launch that may defer paths to the queue; 2: the launch that drains the queue
-    constexpr bool DRAIN = MODE == 2, DEFER = MODE == 1;
+    // MODE 0: plain launch; 1: launch that may defer paths to the queue; 2: the launch that drains the queue;
+    // 3: plain launch of whole-pixel work items (no sample records: the lane adds its pixel's samples up itself)
+    constexpr bool DRAIN = MODE == 2, DEFER = MODE == 1, WHOLE = MODE == 3;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
     // traversal stack: entry 0 of every lane holds a sentinel that ends the walk when it is popped.  References are
@@ -228,7 +229,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
 
     uint32_t phase = PH_FETCH;
     uint32_t px = 0, ply = 0, s = 0, s_end = 0, depth_left = 0, natt = 0;
-    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    V3 sum = mk(0.0f, 0.0f, 0.0f); // WHOLE only: the pixel's running sum
     Rng rng{};
     Trav t{};
     t.cur = kStackEnd; // "not walking" (see the traversal loop)
@@ -242,7 +243,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
     // write-backs per 1080p x 512 spp frame, all of it this strip.
     const uint32_t maxdepth = P.cam.maxdepth;
     uint32_t run_h = 0, run_n = 0;
-    uint32_t npend = 0; // 1: a finished sample waits in `sum` for its partner of the same 32-byte sector
     // LDS-resident scenes: closed runs go through a window of kAttLds (4) entries in LDS; a full window leaves as ONE
     // 16-byte store to the lane's strip in HBM, so a path whose material changes at every bounce (the box of config 5:
     // 79 segments per sample) moves 4 bytes per bounce instead of the two lone 4-byte stores it used to cost
@@ -412,7 +412,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                 if (px < W && ply < P.n_local_rows) {
                     s = chunk_id * P.chunk;
                     s_end = min(spp, s + P.chunk);
-                    sum = mk(0.0f, 0.0f, 0.0f);
+                    if (WHOLE) sum = mk(0.0f, 0.0f, 0.0f);
                     phase = PH_GEN;
                 }
             }
@@ -726,12 +726,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                             }
                         }
                         if (deferred) {
-                            // the drain launch will store (and count) this sample; write out the finished ones that
-                            // were waiting for it and move on to the next one
-                            if (npend > 0u) {
-                                P.sample_buf[(size_t)((size_t)ply * W + px) * spp + (s - 1u)] = make_float4(sum.x, sum.y, sum.z, 0.0f);
-                                npend = 0u;
-                            }
+                            // the drain launch will store (and count) this sample; move on to the next one
                             s++;
                             phase = (s >= s_end) ? PH_FETCH : PH_GEN;
                         } else {
@@ -773,25 +768,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
             ISA_MARK("shade-ended");
             if (ended) {
                 // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
-                if (P.sample_buf) {
-                    // 16-byte sample records, written a 32-byte sector at a time: an even sample waits in registers for
-                    // its odd partner (or the end of the chunk), so that the two stores hit L2 back to back and leave
-                    // it as one full sector (a lone 16-byte store costs ~43 bytes of write-back at the fabric, measured)
-                    if ((s & 1u) == 1u || s + 1u >= s_end) {
-                        float4* dst = P.sample_buf + (size_t)((size_t)ply * W + px) * spp + (s - npend);
-                        if (npend > 0u) dst[0] = make_float4(sum.x, sum.y, sum.z, 0.0f);
-                        dst[npend] = make_float4(color.x, color.y, color.z, 0.0f);
-                        npend = 0u;
-                    } else {
-                        sum = color; // `sum` is free in this mode: it holds the waiting sample
-                        npend = 1u;
-                    }
+                if (!WHOLE) {
+                    // one 16-byte record per sample, stored as soon as the sample is finished.  (Round 1 kept an even sample in
+                    // three registers until its odd partner could leave with it as one 32-byte sector: half the write-backs at
+                    // the fabric, but the path is not bound by HBM and the registers are worth more.)
+                    P.sample_buf[(size_t)((size_t)ply * W + px) * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
                 } else {
                     sum = vadd(sum, color);
                 }
                 s++;
                 if (STATS) st_samples++;
-                if (s >= s_end && P.sample_buf) {
+                if (s >= s_end && !WHOLE) {
                     phase = PH_FETCH; // chunk done; rtmi_resolve_kernel finishes the pixel
                 } else if (s >= s_end) {
                     const V3 outc = vscale(sum, P.cam.pixels_sample_scale);
@@ -981,14 +968,17 @@ namespace {
 
 using KernelFn = void (*)(const RtmiLaunch);
 
-template <int ACCEL>
+template <int ACCEL, int MODE>
 KernelFn pick_variant(bool stats, bool big) {
-    if (big) return stats ? rtmi_trace_kernel<ACCEL, true, true, 0> : rtmi_trace_kernel<ACCEL, false, true, 0>;
-    return stats ? rtmi_trace_kernel<ACCEL, true, false, 0> : rtmi_trace_kernel<ACCEL, false, false, 0>;
+    if (big) return stats ? rtmi_trace_kernel<ACCEL, true, true, MODE> : rtmi_trace_kernel<ACCEL, false, true, MODE>;
+    return stats ? rtmi_trace_kernel<ACCEL, true, false, MODE> : rtmi_trace_kernel<ACCEL, false, false, MODE>;
 }
 
-KernelFn pick_kernel(uint32_t accel, bool stats, bool big) {
-    return accel == RTMI_ACCEL_BVH ? pick_variant<RTMI_ACCEL_BVH>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE>(stats, big);
+// whole_pixels: work items are whole pixels (no sample-record buffer): MODE 3, the lane keeps the pixel's sum
+KernelFn pick_kernel(uint32_t accel, bool stats, bool big, bool whole_pixels) {
+    if (whole_pixels)
+        return accel == RTMI_ACCEL_BVH ? pick_variant<RTMI_ACCEL_BVH, 3>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE, 3>(stats, big);
+    return accel == RTMI_ACCEL_BVH ? pick_variant<RTMI_ACCEL_BVH, 0>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE, 0>(stats, big);
 }
 
 // the drain launch exists for LDS-resident BVH scenes only (that is where paths are deferred)
@@ -1177,7 +1167,8 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         const int rc = rtmi_wavefront_launch(P, s->collect_stats, s->big, s->wf_wpe, s->wf_grid, s->wf_block, s->wf_lds_bytes, stream);
         if (rc != RTMI_OK) return rc;
     } else {
-        KernelFn fn = P.defer_buf ? pick_defer_kernel(s->collect_stats) : pick_kernel(s->accel, s->collect_stats, s->big);
+        KernelFn fn = P.defer_buf ? pick_defer_kernel(s->collect_stats)
+                                  : pick_kernel(s->accel, s->collect_stats, s->big, P.sample_buf == nullptr);
         void* args[] = {&P};
         HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
     }
@@ -1496,9 +1487,11 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     }
 
     // persistent grid: exactly as many workgroups as the device keeps resident
-    KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big);
+    KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big, false);
     HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)s->lds_bytes));
+    HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s->accel, s->collect_stats, s->big, true)),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
     if (!s->big && s->accel == RTMI_ACCEL_BVH) {
         HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_drain_kernel(s->collect_stats)),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
