@@ -222,13 +222,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         lds_nodes = w_nodes;
     }
 
-    const uint32_t lane = lane_id();
-    const uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
+    // (functions, not values: these are needed once per path or per launch and must not hold a register in between)
+    auto glane_of = [&]() -> uint32_t { return blockIdx.x * blockDim.x + threadIdx.x; };
+#define glane glane_of()
+#define lane lane_id()
     const uint32_t W = P.cam.img_width;
     const uint32_t spp = P.cam.samples_per_pixel;
 
     uint32_t phase = PH_FETCH;
-    uint32_t px = 0, ply = 0, s = 0, s_end = 0, depth_left = 0, natt = 0;
+    uint32_t lpix = 0, s = 0, s_end = 0, depth_left = 0, natt = 0; // lpix: pixel index within this call's rows
     V3 sum = mk(0.0f, 0.0f, 0.0f); // WHOLE only: the pixel's running sum
     Rng rng{};
     Trav t{};
@@ -277,12 +279,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         for (uint32_t c = 0; c < n; ++c) color = vmul(a, color); // A*(A*(...)): one multiply per bounce, in order
         return color;
     };
-    const uint32_t sp1 = sp0 + sp_stride;
     // the spheres of one leaf against the current segment, two at a time: both discriminants, then the (rare) roots.
     // The first pair is straight code -- with the default leaf size of 2 it is the whole leaf -- larger leaves loop on
     auto test_leaf = [&](uint32_t ref) {
         const uint32_t first = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
         const uint32_t cnt = BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u);
+        t.a = vdot(t.d, t.d); // (recomputed here: not a register across the node steps)
         const Recip ra = recip_for(t.a); // shared by every root of this leaf step
         auto pair = [&](uint32_t q) {
             const bool two = q + 1u < cnt;
@@ -306,7 +308,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         t.a = vdot(d, d);
         t.tbest = __builtin_inff();
         t.best = ~0u;
-        t.sp = sp1;
+        t.sp = lds0 + P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT) + sp_stride; // entry 1 (entry 0: the sentinel)
         if (ACCEL == RTMI_ACCEL_BVH) {
             t.cur = P.root_ref;
             t.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
@@ -379,14 +381,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     const uint4* rec = P.defer_buf + (size_t)idx * 5u;
                     const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                     if ((r2.x >> 16) == 0u) continue; // empty slot (reserved by a wave, never filled)
-                    px = r1.z & 0xffffu;
-                    ply = r1.z >> 16;
+                    lpix = r1.z;
                     rng.pixel = r1.w;
                     s = r2.x & 0xffffu;
                     s_end = s + 1u;
                     depth_left = r2.x >> 16;
                     rng.k = r2.y;
-                    rng.sample = s;
                     natt = r2.z & 0xffffu;
                     run_n = r2.z >> 16;
                     run_h = r2.w;
@@ -407,9 +407,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                 // bottom rows first: they cost ~5x a sky row, so the tail of the launch is made of cheap pixels
                 const uint32_t trow = fdiv(tile, P.div_tiles_x);
                 const uint32_t tx = tile - trow * P.tiles_x, ty = P.top_down ? trow : P.tiles_y - 1u - trow;
-                px = tx * 8u + (j & 7u);
-                ply = ty * 8u + (j >> 3);
+                const uint32_t px = tx * 8u + (j & 7u), ply = ty * 8u + (j >> 3);
                 if (px < W && ply < P.n_local_rows) {
+                    const uint32_t blk = fdiv(ply, P.div_block_rows); // local row -> row of the whole image
+                    const uint32_t gy = P.y_first + blk * P.block_stride * P.block_rows + (ply - blk * P.block_rows);
+                    lpix = ply * W + px;
+                    rng.pixel = gy * W + px;
                     s = chunk_id * P.chunk;
                     s_end = min(spp, s + P.chunk);
                     if (WHOLE) sum = mk(0.0f, 0.0f, 0.0f);
@@ -424,11 +427,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
         ISA_MARK("gen");
         if (!DRAIN && phase == PH_GEN) {
-            const uint32_t blk = fdiv(ply, P.div_block_rows);
-            const uint32_t gy = P.y_first + blk * P.block_stride * P.block_rows + (ply - blk * P.block_rows);
+            const uint32_t gy = fdiv(rng.pixel, P.div_w), px = rng.pixel - gy * W; // (rng.pixel = gy * W + px came with the work item)
             rng.k = 0;
             rng.sample = s;
-            rng.pixel = gy * W + px;
             Blk gb = rng_block(rng, 0u, P.seed); // draws 0,1: pixel jitter; 2,3: first defocus-disk attempt
             const float offx = draw_centered(gb.w0);
             const float offy = draw_centered(gb.w1);
@@ -617,6 +618,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         if (phase == PH_SHADE && t.best < kBlackSample) rq = lds_aux[t.best].w != 2u ? RQ_UNIT : RQ_WORD;
         PF_MARK(pf8);
         ISA_MARK("draws");
+        rng.sample = s; // (defined where it is used: not a register across the walk)
         const V3 unit_vec = coop_draws(rq, rng, P.seed, rank_tbl);
         ISA_MARK("shade");
         PF_MARK(pf5);
@@ -719,7 +721,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                                     if (q < natt) e[q] = lds_att[q * blockDim.x + threadIdx.x];
                                 }
                                 rec[0] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), __float_as_uint(sd.x));
-                                rec[1] = make_uint4(__float_as_uint(sd.y), __float_as_uint(sd.z), px | (ply << 16), rng.pixel);
+                                rec[1] = make_uint4(__float_as_uint(sd.y), __float_as_uint(sd.z), lpix, rng.pixel);
                                 rec[2] = make_uint4(s | (depth_left << 16), rng.k, natt | (run_n << 16), run_h);
                                 rec[3] = make_uint4(e[0], e[1], e[2], e[3]);
                                 deferred = true;
@@ -772,7 +774,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     // one 16-byte record per sample, stored as soon as the sample is finished.  (Round 1 kept an even sample in
                     // three registers until its odd partner could leave with it as one 32-byte sector: half the write-backs at
                     // the fabric, but the path is not bound by HBM and the registers are worth more.)
-                    P.sample_buf[(size_t)((size_t)ply * W + px) * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
+                    P.sample_buf[(size_t)lpix * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
                 } else {
                     sum = vadd(sum, color);
                 }
@@ -782,7 +784,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
                     phase = PH_FETCH; // chunk done; rtmi_resolve_kernel finishes the pixel
                 } else if (s >= s_end) {
                     const V3 outc = vscale(sum, P.cam.pixels_sample_scale);
-                    const size_t o = (size_t)ply * W + px;
+                    const size_t o = lpix;
                     if (P.out_rgb) {
                         P.out_rgb[3 * o + 0] = outc.x;
                         P.out_rgb[3 * o + 1] = outc.y;
@@ -830,6 +832,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launc
         atomicAdd(&P.stats[3], (unsigned long long)st_node);
     }
 }
+
+#undef glane
+#undef lane
 
 // Ordered resolve of the sample-chunk split: pixel_color += sample, s = 0 .. spp-1, exactly the sequential fp32 sum of
 // raytrace_pixel (core.cc:260-263), then * pixels_sample_scale and RGBAColor (core.cc:264, color.hpp:30-36).
@@ -1115,9 +1120,8 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     // A/B on MI355X, 1080p x 512 spp split over N ranks: the drain launch pays off for the whole frame (+2 %), half of
     // it (+1.8 %) and a quarter (+0.6 %); for an eighth (133 M samples, 340 per lane) its own ramp and tail cost 3 %
     const bool defer_pays = (uint64_t)n_local_rows * W * spp >= 512ull * s->grid * s->block;
-    // (a queue record packs the pixel as x | y << 16: launches wider or taller than 65535 keep their paths)
     if (P.sample_buf && (s->defer_mode == 1 || (s->defer_mode == 2 && defer_pays)) && !s->big &&
-        s->accel == RTMI_ACCEL_BVH && s->cam.maxdepth >= 16 && W <= 0xffffu && n_local_rows <= 0xffffu) {
+        s->accel == RTMI_ACCEL_BVH && s->cam.maxdepth >= 16) {
         uint64_t want = std::min<uint64_t>((uint64_t)n_local_rows * W * spp / 16u + 65536u, 0x7fffffffull / 5u);
         if (s->defer_cap_req) want = std::max<uint64_t>(64u, s->defer_cap_req); // tests: force overflow
         if (want > s->defer_cap) {
@@ -1141,6 +1145,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.div_tiles_x = make_fastdiv(P.tiles_x);
     P.div_chunks = make_fastdiv(P.n_chunks);
     P.div_block_rows = make_fastdiv(P.block_rows);
+    P.div_w = make_fastdiv(W);
     P.wait_thresh = s->wait_thresh;
     P.seed = seed;
     P.out_rgb = d_rgb;
@@ -1162,7 +1167,6 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         P.lds_wf_rings = s->wf_lds_rings;
         P.lds_wf_ctrl = s->wf_lds_ctrl;
         P.wf_refill = s->wf_refill;
-        P.div_w = make_fastdiv(W);
         P.wf_error = s->d_wf_error;
         const int rc = rtmi_wavefront_launch(P, s->collect_stats, s->big, s->wf_wpe, s->wf_grid, s->wf_block, s->wf_lds_bytes, stream);
         if (rc != RTMI_OK) return rc;

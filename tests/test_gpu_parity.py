@@ -506,9 +506,9 @@ def test_multi_device_frame_entry_degenerate_one_device(pkg, ob, rtow, gpu):
     assert torch.cuda.current_device() == 0  # every entry point restores the caller's device
 
 
-def test_images_wider_than_a_queue_record_can_address(pkg, ob, gpu):
-    """A deferred-path record packs the pixel as x | y << 16: a launch wider than 65535 pixels must keep its paths (the
-    deferral is a scheduling decision) -- 70000 x 8 with the queue forced on."""
+def test_images_wider_than_16_bit_coordinates(pkg, ob, gpu):
+    """A deferred-path record holds the pixel's index within the call (32 bits; round 1 packed x | y << 16 and had to keep
+    the paths of launches wider than 65535 pixels) -- 70000 x 8 with the queue forced on."""
     objs, mats = three_spheres()
     kw = dict(three_spheres_camera(), image_width=70000, aspect_ratio=70000.0 / 8.0, samples_per_pixel=8, max_depth=24)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
