@@ -51,7 +51,7 @@ CONFIGS = {
               name="RTOW final scene 1920x1080, 512 spp, 50 bounces"),
     "4": dict(scene="grid", width=1920, spp=256, depth=50, lin=(128, 34, 4), cpu_stride=64,
               name="100k random spheres with full BVH, 1920x1080, 256 spp"),
-    "5": dict(scene="cornell", width=800, spp=4096, depth=200, lin=(96, 25, 4), cpu_stride=4,
+    "5": dict(scene="cornell", width=800, spp=4096, depth=200, lin=(96, 25, 4), cpu_stride=8,
               name="Cornell-box-style enclosed scene, 800x800, 4096 spp, 200 bounces"),
 }
 
