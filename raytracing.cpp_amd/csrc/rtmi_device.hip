@@ -166,7 +166,9 @@ DEV void walk_nodes_lds(Trav& t, uint32_t nbase, uint32_t stride, int floor, int
 template <int ACCEL, bool STATS, bool BIG, int MODE>
 // 6 waves per SIMD (<= 80 VGPRs): two workgroups of 768 lanes per CU; that occupancy is worth +17 % over 4 waves per
 // SIMD (measured), and one register more would silently halve it -- hence the explicit bound
-__global__ void __attribute__((amdgpu_waves_per_eu(RTMI_WPE, RTMI_WPE))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
+// (HBM-resident scenes wait on their node reads, not on issue slots: their variants are allocated for 8 waves per SIMD --
+// 64 VGPRs, which they fit without spilling -- and run as two 896-lane workgroups per CU, 7 waves per SIMD: -3.4 %)
+__global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 : RTMI_WPE))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     // MODE 0: plain launch; 1: launch that may defer paths to the queue; 2: the launch that drains the queue;
     // 3: plain launch of whole-pixel work items (no sample records: the lane adds its pixel's samples up itself)
     constexpr bool DRAIN = MODE == 2, DEFER = MODE == 1, WHOLE = MODE == 3;
@@ -1376,6 +1378,12 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     s->big = small_total + kAttLds * s->block * 4u > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u ||
              n_objects > 0x2000u || n_materials > 0x10000u;
     if (tune.force_hbm_scene) s->big = true;
+    // HBM-resident scenes: the largest workgroup of which two fit the LDS with their stacks, up to 896 lanes (7 waves per
+    // SIMD; 1024 would need 80 KB of stack at the depth of a 100k-sphere tree)
+    if (s->big && !tune.block_lanes && s->accel == RTMI_ACCEL_BVH) {
+        s->block = 896u;
+        while (s->block > 768u && (uint64_t)s->stack_depth * s->block * 4u + (s->block / 64u) * 80u + 64u > 80u * 1024u) s->block -= 64u;
+    }
     uint32_t off = 0;
     if (!s->big) {
         s->lds_nodes = off;
