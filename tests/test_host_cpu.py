@@ -81,6 +81,10 @@ def test_scene_create_argument_errors(pkg):
     assert e.value.code == pkg.RTMI_ERR_BAD_ARG
     assert pkg.lib().rtmi_scene_create(None, None, 0, None, 0, None, None) == pkg.RTMI_ERR_BAD_ARG
     assert pkg.lib().rtmi_render_rows(None, 0, 1, 0, None, None) == pkg.RTMI_ERR_BAD_ARG
+    info = pkg.LaunchInfo()
+    info.struct_size = C.sizeof(pkg.LaunchInfo)
+    assert pkg.lib().rtmi_scene_get_launch_info(None, C.byref(info)) == pkg.RTMI_ERR_BAD_ARG
+    assert C.sizeof(pkg.LaunchInfo) == 32
     pkg.lib().rtmi_scene_destroy(None)  # no-op
 
 
