@@ -1084,17 +1084,18 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.n_chunks = 1;
     P.sample_buf = nullptr;
     const size_t sample_floats = (size_t)n_local_rows * W * spp; // float4 records
-    // chunk size: aim at ~128 work items per lane of the persistent grid, never below 2 samples.  The end of a launch is
+    // chunk size: aim at ~128 work items per lane of the persistent grid, never below 3 samples.  The end of a launch is
     // a tail of lanes finishing their last item while the others idle, so items must be short next to the launch
     // (A/B on MI355X, 1080p x 512 spp, ms per launch: whole frame 4: 223.1, 8: 219.1, 16: 217.8, 24: 217.6, 32: 219.0,
     // 86: 235.4; the eighth of the frame one of 8 GPUs renders 2: 28.5, 3: 28.0, 4: 28.0, 6: 28.6, 16: 36.2;
-    // config 2, 1200 x 675 x 100 spp, 206 samples per lane: 2: 17.1, 4: 17.5, 8: 18.8, 16: 22.7)
+    // config 2, 1200 x 675 x 100 spp, 206 samples per lane: 2: 17.1, 4: 17.5, 8: 18.8, 16: 22.7; on the round-2 kernel
+    // 1: 15.6, 2: 12.0, 3: 11.4, 4: 11.4)
     uint32_t chunk = s->chunk;
     if (chunk == ~0u) {
         const uint64_t want_items = 128ull * s->grid * s->block;
         const uint64_t pixels = (uint64_t)n_local_rows * W;
         const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, (want_items + pixels - 1) / pixels);
-        chunk = std::max(2u, (spp + n_chunks - 1u) / std::max(1u, n_chunks));
+        chunk = std::max(3u, (spp + n_chunks - 1u) / std::max(1u, n_chunks));
     }
     if (chunk && spp > chunk && sample_floats * sizeof(float4) <= s->sample_buf_cap_bytes) {
         if (sample_floats > s->samples_capacity) {
