@@ -108,14 +108,16 @@ typedef struct rtmi_tuning {
     uint32_t block_lanes;       /* lanes per workgroup, multiple of 64 (default 768: 2 x 768 per CU = 6 waves per SIMD) */
     uint32_t blocks_per_cu;     /* cap on resident workgroups per CU (default: the occupancy query) */
     uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 52) */
-    uint32_t drain_wait_thresh; /* the same for the launch that finishes deferred paths (default 56) */
+    uint32_t reserved0;         /* (was drain_wait_thresh: the deferred-path queue of rounds 1-2 is gone) must be 0 */
     int32_t chunk_samples;      /* samples per work item: 0 = auto, -1 = whole pixels (no sample records), n > 0 = n */
-    int32_t defer_mode;         /* deferred-path queue + drain launch: 0 = default (off), 1 = on, 2 = on for long launches, -1 = off */
-    uint32_t defer_cap;         /* capacity of that queue in records (default: 1/16 of the samples of the launch) */
+    int32_t reserved1;          /* (was defer_mode) ignored */
+    uint32_t reserved2;         /* (was defer_cap) ignored */
     uint32_t sample_buf_mb;     /* cap on the sample-record buffer in MiB (default 24576); larger calls run in row bands */
     uint32_t force_hbm_scene;   /* nonzero: leave the scene in HBM even when it fits LDS (the config-4 path) */
     uint32_t top_down;          /* nonzero: hand out tiles top row first instead of bottom row first */
-    uint32_t kernel;            /* BVH scenes: 0 = library default, 1 = round-based kernel, 2 = queue-scheduled kernel */
+    uint32_t kernel;            /* BVH scenes: 0 = library default, 1 = round-based kernel, 2 = queue-scheduled kernel
+                                 * (an experiment that lost on every measured workload: RTMI_ERR_UNSUPPORTED unless the
+                                 * library was built with -DRTMI_EXPERIMENTAL, which rtmi_version() then reports) */
     uint32_t wf_block_lanes;    /* queue-scheduled kernel: lanes per workgroup (default 1024: one workgroup per CU) */
     uint32_t wf_slots;          /* its path slots per workgroup (default: as many as LDS holds, at most 2 per lane) */
     uint32_t wf_refill;         /* idle lanes at which a traversing wave takes new rays (default 24) */
@@ -201,13 +203,16 @@ int rtmi_scene_get_accel(const rtmi_scene* scene, uint32_t* accel_out);
 /* How rtmi_render_* will launch the trace kernel for this scene (what the tuning and the scene's size resolved to). */
 typedef struct rtmi_launch_info {
     uint32_t struct_size;   /* in: sizeof(rtmi_launch_info) */
-    uint32_t kernel;        /* 1 round-based, 2 queue-scheduled (rtmi_tuning::kernel) */
+    uint32_t kernel;        /* 1 round-based, 2 queue-scheduled (rtmi_tuning::kernel, -DRTMI_EXPERIMENTAL builds only) */
     uint32_t block_lanes;   /* lanes per workgroup */
     uint32_t grid_blocks;   /* persistent workgroups of one launch */
     uint32_t blocks_per_cu; /* resident workgroups per CU */
     uint32_t lds_bytes;     /* dynamic LDS per workgroup */
     uint32_t scene_in_lds;  /* 1: nodes, spheres and materials are staged into LDS; 0: read from HBM through the caches */
     uint32_t stack_depth;   /* traversal-stack entries per lane */
+    uint32_t whole_pixel_fallbacks; /* launches so far whose sample-record buffer (16 B per sample of the call, capped by
+                             * rtmi_tuning::sample_buf_mb) could not be allocated: they ran with whole-pixel work items --
+                             * the same image, but a longer tail at the end of the launch */
 } rtmi_launch_info;
 int rtmi_scene_get_launch_info(const rtmi_scene* scene, rtmi_launch_info* out);
 /* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), rmax^2}. */
@@ -228,9 +233,10 @@ int rtmi_scene_last_kernel_ms(rtmi_scene* scene, float* ms_out);
  *      and the per-frame drain of RayTracer::update, main.cc:733-774) -------------------------------------------
  * One process, n devices.  The image plane is sharded by interleaved row blocks (block b -> device b mod n, so the
  * cheap sky rows and the expensive ground rows are spread evenly); every device holds a replica of the scene and
- * renders its blocks into a dense slice; ONE RCCL gather (ncclGather inside ncclGroupStart/End, over xGMI) brings
- * the slices to devices[0], where a small kernel restores scanline order.  The frame is bit-identical for any n
- * (the draw streams are keyed by absolute pixel and sample).  With n == 1 no communicator is created. */
+ * renders its blocks into a dense slice (float RGB and RGBA8 in one buffer); ONE RCCL gather (one ncclGather per rank
+ * inside ncclGroupStart/End, over xGMI) brings the slices to devices[0], where a small kernel restores scanline order.
+ * The frame is bit-identical for any n (the draw streams are keyed by absolute pixel and sample).  With n == 1 no
+ * communicator is created (unless RTMI_FRAME_FORCE_RCCL asks for it). */
 typedef struct rtmi_frame rtmi_frame; /* opaque: scene replicas, streams, slices, RCCL communicators */
 
 typedef struct rtmi_frame_timing {
@@ -242,8 +248,12 @@ typedef struct rtmi_frame_timing {
 /* `options->device` is ignored (the list decides); `devices` = HIP ordinals, distinct, 1 <= n <= 16;
  * `block_rows` = rows per shard block (0 = 8).  Test hook: options->reserved[0] & RTMI_FRAME_REHEARSAL lets a device
  * appear more than once and gathers the slices with plain copies instead of RCCL (which wants one rank per device), so
- * that a one-GPU box can check the shard plan and the scanline order for n > 1. */
+ * that a one-GPU box can check the shard plan and the scanline order for n > 1.  options->reserved[0] &
+ * RTMI_FRAME_FORCE_RCCL creates the communicator and runs the grouped gather for n == 1 as well (rank 0 gathers from
+ * itself), so that librccl, ncclCommInitAll, the gather and its stream ordering against the trace and de-interleave
+ * kernels execute on a one-GPU box. */
 #define RTMI_FRAME_REHEARSAL 1u
+#define RTMI_FRAME_FORCE_RCCL 2u
 int rtmi_frame_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
                       const rtmi_material* materials, uint32_t n_materials, const rtmi_scene_options* options,
                       const int32_t* devices, uint32_t n_devices, uint32_t block_rows, rtmi_frame** out);
@@ -255,7 +265,13 @@ int rtmi_frame_render(rtmi_frame* frame, uint64_t seed, float* rgb_linear_out, u
  * render or destroy) to H*W*3 floats and H*W uint32 in scanline order.  Blocking. */
 int rtmi_frame_render_device(rtmi_frame* frame, uint64_t seed, void** d_rgb_linear, void** d_rgba8);
 int rtmi_frame_get_timing(const rtmi_frame* frame, rtmi_frame_timing* out);
-/* number of RCCL ranks behind the frame (0 when n_devices == 1: no communicator) */
+/* The frame's scene replica on devices[index] (owned by the frame, valid until rtmi_frame_destroy): lets a host that
+ * also wants per-device row-block workers (rtmi_render_rows from one thread per device) use the replicas the frame
+ * already holds instead of creating a second scene -- BVH, strips and sample records -- per device.  A replica must not
+ * be rendered through rtmi_render_* while rtmi_frame_render* is running on the frame. */
+int rtmi_frame_get_scene(rtmi_frame* frame, uint32_t index, rtmi_scene** scene_out);
+/* number of RCCL ranks behind the frame (0 when no communicator exists: n_devices == 1 without RTMI_FRAME_FORCE_RCCL,
+ * or a rehearsal frame) */
 int rtmi_frame_rccl_ranks(const rtmi_frame* frame, uint32_t* n_out);
 
 #ifdef __cplusplus

@@ -78,6 +78,8 @@ def lib():
     L.orc_mt_next_u32.argtypes = [vp]
     L.orc_counter_double.restype = C.c_double
     L.orc_counter_double.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.orc_mix_seed.restype = C.c_uint64
+    L.orc_mix_seed.argtypes = [C.c_uint64]
     L.orc_philox4x32_10.argtypes = [vp, vp, vp]
     L.orc_philox4x32.argtypes = [C.c_int, vp, vp, vp]
     L.orc_pcg4d.argtypes = [vp, vp]

@@ -142,7 +142,7 @@ void orc_set_counter_rng(int kind) { g_counter_rng = kind; }
 int orc_get_counter_rng(void) { return g_counter_rng; }
 void orc_counter_block(uint32_t blk, uint32_t sample, uint32_t pixel, const uint32_t key[2], uint32_t out[4]) {
     if (g_counter_rng == 0) {
-        const uint32_t in[4] = {blk, sample ^ key[1], pixel, key[0]};
+        const uint32_t in[4] = {blk ^ key[1], sample, pixel, key[0]};
         orc_pcg4d(in, out);
     } else {
         const uint32_t ctr[4] = {blk, sample, pixel, 0u};
@@ -236,11 +236,22 @@ void orc_rng_free(orc_rng* r) { free(r); }
 double orc_rng_double(orc_rng* r) { return rd(r); }
 uint32_t orc_mt_next_u32(orc_rng* r) { return mt_next(r); }
 
+/* The two key words of a counter stream: a bijective mix of the caller's 64-bit seed (the splitmix64 finaliser), so that
+ * seeds differing in one bit or only in the high word give unrelated keys and no key word meets the sample index
+ * (build-side: the reference seeds one independent generator per std::random_device value, random.number.gen.hpp:45-46). */
+uint64_t orc_mix_seed(uint64_t seed) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 static void rng_init_counter(orc_rng* r, uint64_t seed) {
     memset(r, 0, sizeof(*r));
     r->kind = ORC_RNG_COUNTER;
-    r->key[0] = (uint32_t)seed;
-    r->key[1] = (uint32_t)(seed >> 32);
+    const uint64_t k = orc_mix_seed(seed);
+    r->key[0] = (uint32_t)k;
+    r->key[1] = (uint32_t)(k >> 32);
 }
 
 double orc_counter_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k) {
@@ -901,12 +912,14 @@ static int render_rect(const orc_camera* cam, const scene_t* sc, uint64_t seed, 
         jobs[t].next_row = &next_row;
         jobs[t].want_ctr = ctr != NULL;
     }
-    if (nthreads == 1) {
-        rect_worker(&jobs[0]);
-    } else {
-        for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, rect_worker, &jobs[t]);
-        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
-    }
+    /* compute_color recurses maxdepth levels (core.cc:247, up to 65535): workers get a 1 GiB stack (reserved, touched on
+     * demand), also the single one -- the caller's own stack may be the 8 MiB default */
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, (size_t)1 << 30);
+    for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], &attr, rect_worker, &jobs[t]);
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    pthread_attr_destroy(&attr);
     if (ctr) {
         for (int t = 0; t < nthreads; ++t) counters_add(ctr, &jobs[t].ctr);
     }

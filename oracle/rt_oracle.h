@@ -106,6 +106,8 @@ orc_rng* orc_rng_new_mt(uint32_t seed);
 void orc_rng_free(orc_rng*);
 double orc_rng_double(orc_rng*);
 uint32_t orc_mt_next_u32(orc_rng*);
+/* the two key words of a counter stream: a bijective mix (splitmix64 finaliser) of the caller's 64-bit seed */
+uint64_t orc_mix_seed(uint64_t seed);
 /* k-th double of the counter stream of (seed, pixel, sample) */
 double orc_counter_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

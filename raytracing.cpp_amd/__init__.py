@@ -18,7 +18,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "librtmi.so")
-CSRC = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_host.cpp", "rtmi_device.hip", "rtmi_wavefront.hip", "rtmi_frame.hip")]
+CSRC = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_host.cpp", "rtmi_device.hip", "rtmi_frame.hip")]
+# the queue-scheduled kernel of round 2 (slower than the round-based one on every measured workload): only
+# in libraries built with -DRTMI_EXPERIMENTAL (build_library(experimental=True) -> librtmi_exp.so, never the default)
+CSRC_EXPERIMENTAL = [os.path.join(_HERE, "csrc", "rtmi_wavefront.hip")]
+EXP_LIB_PATH = os.path.join(_HERE, "librtmi_exp.so")
 HEADERS = [os.path.join(_HERE, "csrc", "rtmi_internal.h"), os.path.join(_HERE, "csrc", "rtmi_kernel_common.h"),
            os.path.join(_ROOT, "include", "rtmi.h")]
 
@@ -36,18 +40,22 @@ RTMI_ERR_BAD_ARG, RTMI_ERR_HIP, RTMI_ERR_OOM, RTMI_ERR_UNSUPPORTED, RTMI_ERR_RCC
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
 
 
-def build_library(force=False, verbose=False):
-    """Compile csrc/ for gfx950 with hipcc into librtmi.so (in-tree, so it travels to the GPU box)."""
-    srcs = CSRC + HEADERS
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
-        return LIB_PATH
+def build_library(force=False, verbose=False, experimental=False):
+    """Compile csrc/ for gfx950 with hipcc into librtmi.so (in-tree, so it travels to the GPU box).
+    experimental=True builds librtmi_exp.so instead: the same sources plus the queue-scheduled kernel."""
+    out = EXP_LIB_PATH if experimental else LIB_PATH
+    csrc = CSRC + (CSRC_EXPERIMENTAL if experimental else [])
+    srcs = csrc + HEADERS
+    if (not force and os.path.exists(out)
+            and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs)):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(_ROOT, "include"), "-o", LIB_PATH] + CSRC + ["-ldl"]
+    cmd = ([hipcc] + HIPCC_FLAGS + (["-DRTMI_EXPERIMENTAL"] if experimental else [])
+           + ["-I", os.path.join(_ROOT, "include"), "-o", out] + csrc + ["-ldl"])
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
 
 
 class CameraParams(C.Structure):  # rtmi_camera_params == reference src/camera.parameters.hpp:6-17
@@ -73,8 +81,8 @@ class WorldDef(C.Structure):  # rtmi_world_def == reference src/ray.tracer.core.
 
 class Tuning(C.Structure):  # rtmi_tuning: scheduling knobs, 0 = default; none of them changes the image
     _fields_ = [("struct_size", C.c_uint32), ("block_lanes", C.c_uint32), ("blocks_per_cu", C.c_uint32),
-                ("wait_thresh", C.c_uint32), ("drain_wait_thresh", C.c_uint32), ("chunk_samples", C.c_int32),
-                ("defer_mode", C.c_int32), ("defer_cap", C.c_uint32), ("sample_buf_mb", C.c_uint32),
+                ("wait_thresh", C.c_uint32), ("reserved0", C.c_uint32), ("chunk_samples", C.c_int32),
+                ("reserved1", C.c_int32), ("reserved2", C.c_uint32), ("sample_buf_mb", C.c_uint32),
                 ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("kernel", C.c_uint32),
                 ("wf_block_lanes", C.c_uint32), ("wf_slots", C.c_uint32), ("wf_refill", C.c_uint32),
                 ("reserved", C.c_uint32 * 1)]
@@ -87,7 +95,7 @@ class SceneOptions(C.Structure):
 
 class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("struct_size", "kernel", "block_lanes", "grid_blocks", "blocks_per_cu",
-                                          "lds_bytes", "scene_in_lds", "stack_depth")]
+                                          "lds_bytes", "scene_in_lds", "stack_depth", "whole_pixel_fallbacks")]
 
 
 class FrameTiming(C.Structure):
@@ -98,7 +106,7 @@ def make_tuning(**kw):
     """rtmi_tuning from keyword arguments (field names of include/rtmi.h); unknown names are an error."""
     t = Tuning()
     t.struct_size = C.sizeof(Tuning)
-    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved"}
+    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved", "reserved0", "reserved1", "reserved2"}
     for k, v in kw.items():
         if k not in names:
             raise KeyError(f"unknown tuning knob {k!r}")
@@ -133,7 +141,7 @@ EXPORTS = ("rtmi_camera_setup", "rtmi_make_world_spheres", "rtmi_scene_create", 
            "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_last_error", "rtmi_version",
            "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_launch_info", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
            "rtmi_bvh_build", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
-           "rtmi_frame_render_device", "rtmi_frame_get_timing", "rtmi_frame_rccl_ranks")
+           "rtmi_frame_render_device", "rtmi_frame_get_timing", "rtmi_frame_rccl_ranks", "rtmi_frame_get_scene")
 
 _lib = None
 
@@ -182,11 +190,17 @@ def lib():
     L.rtmi_frame_render_device.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
     L.rtmi_frame_get_timing.argtypes = [vp, C.POINTER(FrameTiming)]
     L.rtmi_frame_rccl_ranks.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.rtmi_frame_get_scene.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     for name in EXPORTS:
         if name not in ("rtmi_last_error", "rtmi_version", "rtmi_scene_destroy", "rtmi_frame_destroy"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def experimental():
+    """True when the loaded library was built with -DRTMI_EXPERIMENTAL (carries the queue-scheduled kernel)."""
+    return b"experimental" in lib().rtmi_version()
 
 
 def _check(rc):
@@ -339,11 +353,13 @@ class Frame:
     interleaved row-block shards, one RCCL gather to devices[0]."""
 
     def __init__(self, cam, objs, mats, devices=(0,), block_rows=8, accel=ACCEL_AUTO, leaf_size=0, tuning=None,
-                 rehearsal=False):
+                 rehearsal=False, force_rccl=False):
         objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
         mats = np.ascontiguousarray(mats, dtype=MATERIAL_DTYPE)
         opt, _tun = _options(accel, leaf_size, -1, False, tuning)
-        opt.reserved[0] = 1 if rehearsal else 0  # RTMI_FRAME_REHEARSAL: repeated devices, copies instead of RCCL
+        # RTMI_FRAME_REHEARSAL (1): repeated devices, copies instead of RCCL; RTMI_FRAME_FORCE_RCCL (2): a communicator and
+        # the grouped gather even for one device
+        opt.reserved[0] = (1 if rehearsal else 0) | (2 if force_rccl else 0)
         devs = (C.c_int32 * len(devices))(*devices)
         self._h = C.c_void_p()
         self.width, self.height, self.n_devices = cam.img_width, cam.img_height, len(devices)

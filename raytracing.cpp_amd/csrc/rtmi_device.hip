@@ -23,8 +23,6 @@
 //  * random_unit_vector: the owner lane makes its first two attempts, the wave shares the retries (coop_draws).
 //  * the reference's fp32 divisions and square roots run as the in-range cores of the compiler's own expansions
 //    (bit-identical, a third of the instructions), the full expansions behind a branch for operands out of range.
-//  * paths that turn out to bounce inside an opaque sphere are deferred to a compacted queue and finished by a
-//    second launch (DRAIN variant) whose lanes all walk such paths -- for launches long enough to pay for it.
 //  * scene (BVH nodes, spheres, materials) staged once per workgroup into LDS with coalesced 16-byte loads; the
 //    per-lane traversal stack lives in LDS too.  Scenes that do not fit stay in HBM (BIG variant) behind L2 / Infinity Cache.
 //  * counter RNG: a block function (pcg4d; Philox4x32 in the A/B) of (seed, draw block, sample, pixel): the image does not depend on
@@ -161,17 +159,16 @@ DEV void walk_nodes_lds(Trav& t, uint32_t nbase, uint32_t stride, int floor, int
 // BIG = false: the whole scene is staged into LDS and stack entries are packed into 16 bits (<= 8192 spheres).
 // BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
 //              32-bit entries (config 4: 100k spheres, 2.4 MB of spheres + 6.4 MB of nodes).
-// DRAIN = true: the launch that finishes the deferred paths (work items are queue records; no primary rays, no
-// chunk bookkeeping, no further deferral) -- same arithmetic, leaner control flow.
 template <int ACCEL, bool STATS, bool BIG, int MODE>
 // 6 waves per SIMD (<= 80 VGPRs): two workgroups of 768 lanes per CU; that occupancy is worth +17 % over 4 waves per
 // SIMD (measured), and one register more would silently halve it -- hence the explicit bound
 // (HBM-resident scenes wait on their node reads, not on issue slots: their variants are allocated for 8 waves per SIMD --
 // 64 VGPRs, which they fit without spilling -- and run as two 896-lane workgroups per CU, 7 waves per SIMD: -3.4 %)
 __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 : RTMI_WPE))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
-    // MODE 0: plain launch; 1: launch that may defer paths to the queue; 2: the launch that drains the queue;
-    // 3: plain launch of whole-pixel work items (no sample records: the lane adds its pixel's samples up itself)
-    constexpr bool DRAIN = MODE == 2, DEFER = MODE == 1, WHOLE = MODE == 3;
+    // MODE 0: work items are chunks of a pixel's samples, one 16-byte record per sample; 3: whole-pixel work items (no
+    // sample records: the lane adds its pixel's samples up itself).  (Modes 1 / 2, the deferred-path queue and its drain
+    // launch of rounds 1-2, were measured 8 % slower on the final round-2 kernel and are gone: DESIGN.md 5.1.)
+    constexpr bool WHOLE = MODE == 3;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
     // traversal stack: entry 0 of every lane holds a sentinel that ends the walk when it is popped.  References are
@@ -184,9 +181,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
     auto stack_at = [](uint32_t addr) -> lds_stack_t* { return (lds_stack_t*)(uintptr_t)addr; };
     if (ACCEL == RTMI_ACCEL_BVH) *stack_at(sp0) = (StackS)-1;
     uint32_t* lds_att = reinterpret_cast<uint32_t*>(lds_raw + P.lds_att);
-    // per-wave pools: work indices and deferred-path slots are taken from the global counters 64 at a time (a single
-    // counter word saturates at ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M
-    // work items and 35 M deferred paths)
+    // per-wave pools: work indices are taken from the global counter 64 at a time (a single counter word saturates at
+    // ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M work items)
     uint32_t* pool = reinterpret_cast<uint32_t*>(lds_raw + P.lds_pool) + (threadIdx.x >> 6) * 20u;
     lds_u8* rank_tbl = (lds_u8*)(pool + 4); // 64 bytes, see coop_draws
     if ((threadIdx.x & 63u) == 0u) {
@@ -375,33 +371,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             take = __shfl(take, leader);
             if (rank >= take) continue; // pool ran dry mid-request: ask again
             const uint32_t idx = start + rank;
-            if (DRAIN) {
-                // drain launch: a work item is one deferred path; resume it exactly where the primary launch left it
-                if (idx >= min(*P.defer_count, P.defer_cap)) {
-                    phase = PH_DONE;
-                } else {
-                    const uint4* rec = P.defer_buf + (size_t)idx * 5u;
-                    const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                    if ((r2.x >> 16) == 0u) continue; // empty slot (reserved by a wave, never filled)
-                    lpix = r1.z;
-                    rng.pixel = r1.w;
-                    s = r2.x & 0xffffu;
-                    s_end = s + 1u;
-                    depth_left = r2.x >> 16;
-                    rng.k = r2.y;
-                    natt = r2.z & 0xffffu;
-                    run_n = r2.z >> 16;
-                    run_h = r2.w;
-                    const uint32_t e[4] = {r3.x, r3.y, r3.z, r3.w};
-#pragma unroll
-                    for (uint32_t q = 0; q < 4u; ++q) {
-                        if (q < natt) lds_att[q * blockDim.x + threadIdx.x] = e[q];
-                    }
-                    t.o = mk(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
-                    t.d = mk(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
-                    phase = PH_BEGIN;
-                }
-            } else if (idx >= P.n_work) {
+            if (idx >= P.n_work) {
                 phase = PH_DONE;
             } else {
                 const uint32_t unit = idx >> 6, j = idx & 63u;
@@ -428,7 +398,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
 
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
         ISA_MARK("gen");
-        if (!DRAIN && phase == PH_GEN) {
+        if (phase == PH_GEN) {
             const uint32_t gy = fdiv(rng.pixel, P.div_w), px = rng.pixel - gy * W; // (rng.pixel = gy * W + px came with the work item)
             rng.k = 0;
             rng.sample = s;
@@ -694,50 +664,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                     if (depth_left == 0) {
                         ended = true; // the next compute_color call returns 0 (core.cc:238-240)
                     } else {
-                        bool deferred = false;
-                        if (DEFER && !BIG && P.defer_buf && !front && kind != 2u && natt < 4u && depth_left >= 8u) {
-                            // wave-aggregated append to the deferred-path queue (ballot + prefix popcount)
-                            const uint64_t m = ballot(true);
-                            const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            uint32_t sstart = 0, stake = 0;
-                            if (rk == 0) { // slots come from the wave's pool, reserved 64 at a time
-                                uint32_t next = pool[2], end = pool[3];
-                                if (next == end) {
-                                    next = atomicAdd(P.defer_count, 64u);
-                                    end = next + 64u;
-                                    pool[3] = end;
-                                }
-                                stake = min((uint32_t)__popcll(m), end - next);
-                                sstart = next;
-                                pool[2] = next + stake;
-                            }
-                            const int ld = __ffsll((long long)m) - 1;
-                            sstart = __shfl(sstart, ld);
-                            stake = __shfl(stake, ld);
-                            const uint32_t slot = sstart + rk;
-                            if (rk < stake && slot < P.defer_cap) {
-                                uint4* rec = P.defer_buf + (size_t)slot * 5u;
-                                uint32_t e[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                                for (uint32_t q = 0; q < 4u; ++q) {
-                                    if (q < natt) e[q] = lds_att[q * blockDim.x + threadIdx.x];
-                                }
-                                rec[0] = make_uint4(__float_as_uint(p.x), __float_as_uint(p.y), __float_as_uint(p.z), __float_as_uint(sd.x));
-                                rec[1] = make_uint4(__float_as_uint(sd.y), __float_as_uint(sd.z), lpix, rng.pixel);
-                                rec[2] = make_uint4(s | (depth_left << 16), rng.k, natt | (run_n << 16), run_h);
-                                rec[3] = make_uint4(e[0], e[1], e[2], e[3]);
-                                deferred = true;
-                            }
-                        }
-                        if (deferred) {
-                            // the drain launch will store (and count) this sample; move on to the next one
-                            s++;
-                            phase = (s >= s_end) ? PH_FETCH : PH_GEN;
-                        } else {
-                            t.o = p;
-                            t.d = sd;
-                            phase = PH_BEGIN; // set up before the next traversal, together with the new primary rays
-                        }
+                        t.o = p;
+                        t.d = sd;
+                        phase = PH_BEGIN; // set up before the next traversal, together with the new primary rays
                     }
                 }
             } else {
@@ -811,15 +740,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
         ISA_MARK("loop-end");
     }
 
-    if (DEFER && P.defer_buf && lane == 0u) { // reserved but unused slots become empty records (depth 0)
-        for (uint32_t q = pool[2]; q < pool[3]; ++q) {
-            if (q < P.defer_cap) P.defer_buf[(size_t)q * 5u + 2u] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
 #ifdef RTMI_PROF
     PF_MARK(pf9);
     if (lane == 0) {
-        unsigned long long* const pst = P.stats + (DRAIN ? 32 : 0); // the drain launch reports into its own block
+        unsigned long long* const pst = P.stats;
         atomicAdd(&pst[8], pf0); atomicAdd(&pst[9], pf1); atomicAdd(&pst[10], pf2); atomicAdd(&pst[11], pf3);
         atomicAdd(&pst[12], pf4); atomicAdd(&pst[13], pf5); atomicAdd(&pst[14], pf6); atomicAdd(&pst[15], pf7);
         atomicAdd(&pst[16], pf8); atomicAdd(&pst[17], pf9); atomicAdd(&pst[18], pf10); atomicAdd(&pst[19], pf11);
@@ -941,11 +865,11 @@ struct rtmi_scene {
     size_t samples_capacity = 0; // records
     uint32_t chunk = ~0u;        // samples per work item of the split; ~0u: chosen per launch, 0: split off
     size_t sample_buf_cap_bytes = (size_t)24 << 30; // above this the split is off and a lane owns a whole pixel
-    hipEvent_t ev2 = nullptr;    // end of the trace kernels (ev1 = end of the launch, resolve included)
-    uint4* d_defer = nullptr;    // deferred-path queue
-    uint32_t defer_cap = 0;
-    int defer_mode = 0;        // 0 off (default since the cheaper draw streams: A/B in DESIGN.md), 1 on, 2 on for long launches
-    uint32_t defer_cap_req = 0; // rtmi_tuning::defer_cap (0: sized from the launch)
+    // HIP events around the trace kernel of every band of the most recent call (a banded call interleaves trace and
+    // resolve launches; rtmi_scene_last_kernel_ms adds the trace intervals up)
+    std::vector<hipEvent_t> ev_trace; // [2 * band]: before / after that band's trace kernel
+    uint32_t n_bands_timed = 0;
+    uint32_t whole_pixel_fallbacks = 0; // launches that could not get their sample-record buffer
     bool top_down = false;
     // launch geometry
     uint32_t block = 768, grid = 0, lds_bytes = 0, stack_depth = 0; // 2 x 768 lanes per CU = 6 waves per SIMD (<= 80 VGPRs)
@@ -955,7 +879,6 @@ struct rtmi_scene {
     uint32_t wait_thresh = 52;
     uint32_t lds_att = 0, lds_pool = 0;
     uint32_t n_cus = 0;
-    uint32_t drain_wait_thresh = 56;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     uint32_t pre_leaf_dev[4] = {}; // leaves peeled off the top of the tree, tested at segment set-up
     uint32_t n_pre_leaves = 0;
@@ -988,16 +911,6 @@ KernelFn pick_kernel(uint32_t accel, bool stats, bool big, bool whole_pixels) {
     return accel == RTMI_ACCEL_BVH ? pick_variant<RTMI_ACCEL_BVH, 0>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE, 0>(stats, big);
 }
 
-// the drain launch exists for LDS-resident BVH scenes only (that is where paths are deferred)
-KernelFn pick_drain_kernel(bool stats) {
-    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, false, 2> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, false, 2>;
-}
-
-// the primary launch of a call that defers paths (LDS-resident BVH scenes only)
-KernelFn pick_defer_kernel(bool stats) {
-    return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, false, 1> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, false, 1>;
-}
-
 void free_scene(rtmi_scene* s) {
     if (!s) return;
     hipSetDevice(s->device);
@@ -1011,19 +924,19 @@ void free_scene(rtmi_scene* s) {
     hipFree(s->d_rgb);
     hipFree(s->d_rgba);
     hipFree(s->d_samples);
-    hipFree(s->d_defer);
     hipFree(s->d_wf_error);
-    if (s->ev2) hipEventDestroy(s->ev2);
+    for (hipEvent_t e : s->ev_trace) hipEventDestroy(e);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
 }
 
-// one launch sequence (primary + drain + resolve) over a set of row blocks; `first` / `last`: position within a banded
-// call (the events of rtmi_scene_last_kernel_ms bracket the whole call)
+// one launch sequence (trace + resolve) over a set of row blocks; `band` / `last`: position within a banded call (every
+// band's trace kernel sits between its own pair of events)
 int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks,
-               uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream, bool first, bool last) {
+               uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream, uint32_t band, bool last) {
+    const bool first = band == 0;
     const uint32_t H = s->cam.img_height, W = s->cam.img_width;
     if (block_rows == 0 || block_stride == 0) {
         set_error("rtmi: block_rows and block_stride must be positive");
@@ -1106,37 +1019,13 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
                 s->samples_capacity = sample_floats;
             } else {
                 (void)hipGetLastError(); // not enough HBM for the split: fall back to whole-pixel work items
+                s->whole_pixel_fallbacks++; // (reported by rtmi_scene_get_launch_info: same image, a longer tail)
             }
         }
         if (s->d_samples) {
             P.chunk = chunk;
             P.n_chunks = (spp + chunk - 1u) / chunk;
             P.sample_buf = s->d_samples;
-        }
-    }
-    // deferred-path queue: sized for 6 % of the samples of the launch (the RTOW scene defers 3.3 %); when it fills up
-    // the primary launch simply keeps the path
-    P.defer_buf = nullptr;
-    P.defer_count = s->d_counter + 2;
-    P.defer_cap = 0;
-    P.mode = 0;
-    // A/B on MI355X, 1080p x 512 spp split over N ranks: the drain launch pays off for the whole frame (+2 %), half of
-    // it (+1.8 %) and a quarter (+0.6 %); for an eighth (133 M samples, 340 per lane) its own ramp and tail cost 3 %
-    const bool defer_pays = (uint64_t)n_local_rows * W * spp >= 512ull * s->grid * s->block;
-    if (P.sample_buf && (s->defer_mode == 1 || (s->defer_mode == 2 && defer_pays)) && !s->big &&
-        s->accel == RTMI_ACCEL_BVH && s->cam.maxdepth >= 16) {
-        uint64_t want = std::min<uint64_t>((uint64_t)n_local_rows * W * spp / 16u + 65536u, 0x7fffffffull / 5u);
-        if (s->defer_cap_req) want = std::max<uint64_t>(64u, s->defer_cap_req); // tests: force overflow
-        if (want > s->defer_cap) {
-            hipFree(s->d_defer);
-            s->d_defer = nullptr;
-            s->defer_cap = 0;
-            if (hipMalloc(reinterpret_cast<void**>(&s->d_defer), want * 5u * sizeof(uint4)) == hipSuccess) s->defer_cap = (uint32_t)want;
-            else (void)hipGetLastError();
-        }
-        if (s->d_defer) {
-            P.defer_buf = s->d_defer;
-            P.defer_cap = (uint32_t)std::min<uint64_t>(want, s->defer_cap);
         }
     }
     const uint64_t n_work = (uint64_t)P.tiles_x * ((n_local_rows + 7u) / 8u) * 64u * P.n_chunks;
@@ -1150,7 +1039,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.div_block_rows = make_fastdiv(P.block_rows);
     P.div_w = make_fastdiv(W);
     P.wait_thresh = s->wait_thresh;
-    P.seed = seed;
+    P.seed = mix_seed(seed); // two key words, see rng4x32
     P.out_rgb = d_rgb;
     P.out_rgba = d_rgba;
     P.work_counter = s->d_counter;
@@ -1159,10 +1048,20 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
 
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, 4 * sizeof(uint32_t), stream));
     if (first) HIP_TRY(hipEventRecord(s->ev0, stream));
+    while (s->ev_trace.size() < 2u * (band + 1u)) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        s->ev_trace.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(s->ev_trace[2u * band], stream));
+#ifdef RTMI_EXPERIMENTAL
     // queue-scheduled kernel: needs the sample records (any wave finishes any sample) and a tree to walk
     const bool use_wf = s->wf_enabled && P.sample_buf != nullptr && s->accel == RTMI_ACCEL_BVH;
+#else
+    const bool use_wf = false;
+#endif
     if (use_wf) {
-        P.defer_buf = nullptr;
+#ifdef RTMI_EXPERIMENTAL
         P.lds_stack = s->wf_lds_stack;
         P.wf_slots = s->wf_slots;
         P.wf_cap_mask = s->wf_cap - 1u;
@@ -1173,22 +1072,13 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         P.wf_error = s->d_wf_error;
         const int rc = rtmi_wavefront_launch(P, s->collect_stats, s->big, s->wf_wpe, s->wf_grid, s->wf_block, s->wf_lds_bytes, stream);
         if (rc != RTMI_OK) return rc;
+#endif
     } else {
-        KernelFn fn = P.defer_buf ? pick_defer_kernel(s->collect_stats)
-                                  : pick_kernel(s->accel, s->collect_stats, s->big, P.sample_buf == nullptr);
+        KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big, P.sample_buf == nullptr);
         void* args[] = {&P};
         HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
     }
-    if (P.defer_buf) { // drain launch: same kernel, work items = the queued paths
-        RtmiLaunch D = P;
-        D.mode = 1;
-        D.work_counter = s->d_counter + 1;
-        D.wait_thresh = s->drain_wait_thresh;
-        void* dargs[] = {&D};
-        HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(pick_drain_kernel(s->collect_stats)), dim3(s->grid),
-                                dim3(s->block), dargs, s->lds_bytes, stream));
-    }
-    if (first && last) HIP_TRY(hipEventRecord(s->ev2, stream));
+    HIP_TRY(hipEventRecord(s->ev_trace[2u * band + 1u], stream));
     if (P.sample_buf) {
         const uint32_t n_pixels = n_local_rows * W;
         hipLaunchKernelGGL(rtmi_resolve_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, P.sample_buf,
@@ -1196,8 +1086,8 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         HIP_TRY(hipGetLastError());
     }
     if (last) {
-        if (!first) HIP_TRY(hipEventRecord(s->ev2, stream)); // banded call: trace and resolve launches interleave
         HIP_TRY(hipEventRecord(s->ev1, stream));
+        s->n_bands_timed = band + 1u;
         s->ev_valid = true;
     }
     return RTMI_OK;
@@ -1233,10 +1123,11 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
             if (rows > max_rows) {
                 const uint32_t n_bands = (uint32_t)((rows + max_rows - 1) / max_rows);
                 const uint32_t band = (rows + n_bands - 1) / n_bands;
-                for (uint32_t r0 = 0; r0 < rows; r0 += band) {
+                uint32_t k = 0;
+                for (uint32_t r0 = 0; r0 < rows; r0 += band, ++k) {
                     const uint32_t nr = std::min(band, rows - r0);
                     const int rc = launch_one(s, y_first + r0, nr, 1, 1, seed, d_rgb ? d_rgb + (size_t)r0 * W * 3 : nullptr,
-                                              d_rgba ? d_rgba + (size_t)r0 * W : nullptr, stream, r0 == 0, r0 + nr >= rows);
+                                              d_rgba ? d_rgba + (size_t)r0 * W : nullptr, stream, k, r0 + nr >= rows);
                     if (rc != RTMI_OK) return rc;
                 }
                 return RTMI_OK;
@@ -1245,18 +1136,19 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
             const uint32_t per_band = (uint32_t)(max_rows / block_rows);
             const uint32_t n_bands = (n_blocks + per_band - 1) / per_band;
             const uint32_t per = (n_blocks + n_bands - 1) / n_bands;
-            for (uint32_t b0 = 0; b0 < n_blocks; b0 += per) {
+            uint32_t k = 0;
+            for (uint32_t b0 = 0; b0 < n_blocks; b0 += per, ++k) {
                 const uint32_t nb = std::min(per, n_blocks - b0);
                 const size_t row0 = (size_t)b0 * block_rows;
                 const int rc = launch_one(s, y_first + b0 * block_stride * block_rows, block_rows, block_stride, nb, seed,
                                           d_rgb ? d_rgb + row0 * W * 3 : nullptr, d_rgba ? d_rgba + row0 * W : nullptr,
-                                          stream, b0 == 0, b0 + nb >= n_blocks);
+                                          stream, k, b0 + nb >= n_blocks);
                 if (rc != RTMI_OK) return rc;
             }
             return RTMI_OK;
         }
     }
-    return launch_one(s, y_first, block_rows, block_stride, n_blocks, seed, d_rgb, d_rgba, stream, true, true);
+    return launch_one(s, y_first, block_rows, block_stride, n_blocks, seed, d_rgb, d_rgba, stream, 0u, true);
 }
 
 } // namespace
@@ -1374,10 +1266,12 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     // stay in HBM and only the traversal stack is in LDS.
     auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
     s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) + 2u : 0u; // + the sentinel entry + one spare level (unconditional push store)
+    // (the same expression as the carve-up below, per-wave pools and alignment included: a scene within a kilobyte of the
+    // limit must not end up with one resident workgroup per CU instead of two)
     const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 16u;
-    const uint64_t small_total = scene_bytes + (uint64_t)s->stack_depth * s->block * 2u + 64u;
-    s->big = small_total + kAttLds * s->block * 4u > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u ||
-             n_objects > 0x2000u || n_materials > 0x10000u;
+    const uint64_t small_total = ((scene_bytes + 15u) & ~15ull) + (((uint64_t)s->stack_depth * s->block * 2u + 15u) & ~15ull) +
+                                 (uint64_t)kAttLds * s->block * 4u + (uint64_t)(s->block / 64u) * 80u + 16u;
+    s->big = small_total > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u || n_objects > 0x2000u || n_materials > 0x10000u;
     if (tune.force_hbm_scene) s->big = true;
     // HBM-resident scenes: the largest workgroup of which two fit the LDS with their stacks, up to 896 lanes (7 waves per
     // SIMD; 1024 would need 80 KB of stack at the depth of a 100k-sphere tree)
@@ -1505,12 +1399,6 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
                                   (int)s->lds_bytes));
     HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s->accel, s->collect_stats, s->big, true)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-    if (!s->big && s->accel == RTMI_ACCEL_BVH) {
-        HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_drain_kernel(s->collect_stats)),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-        HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_defer_kernel(s->collect_stats)),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-    }
     int per_cu = 0;
     HIP_TRY_S(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)s->block, s->lds_bytes));
     if (per_cu < 1) {
@@ -1522,15 +1410,31 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     if (tune.blocks_per_cu) per_cu = std::max(1, std::min(per_cu, (int)tune.blocks_per_cu));
     if (tune.wait_thresh) s->wait_thresh = std::min(64u, tune.wait_thresh);
     if (tune.chunk_samples) s->chunk = tune.chunk_samples < 0 ? 0u : (uint32_t)tune.chunk_samples; // 0: split off
-    if (tune.defer_mode) s->defer_mode = tune.defer_mode > 0 ? (tune.defer_mode == 2 ? 2 : 1) : 0;
-    s->defer_cap_req = tune.defer_cap;
-    if (tune.drain_wait_thresh) s->drain_wait_thresh = std::min(64u, tune.drain_wait_thresh);
     if (tune.sample_buf_mb) s->sample_buf_cap_bytes = (size_t)tune.sample_buf_mb << 20;
     s->top_down = tune.top_down != 0;
     s->n_cus = (uint32_t)prop.multiProcessorCount;
     s->grid = s->n_cus * (uint32_t)per_cu;
+    // the per-lane strips of attenuation runs grow with the bounce limit (8 bytes per bounce and lane): beyond 4 GiB the
+    // persistent grid shrinks instead (maxdepth = 65535: 512 KB per lane, ten workgroups) -- slow, correct, never an
+    // allocation the device cannot serve
+    {
+        const uint64_t per_block = (uint64_t)std::max<uint32_t>(1u, camera->maxdepth) * 8u * s->block;
+        const uint64_t fit = std::max<uint64_t>(1u, ((uint64_t)4 << 30) / per_block);
+        if (s->grid > fit) s->grid = (uint32_t)fit;
+    }
 
     // ---- queue-scheduled kernel: slot pool, rings and control words behind the staged scene and the stacks ------------
+    if (tune.kernel > 2u) {
+        set_error("rtmi_scene_create: unknown rtmi_tuning::kernel");
+        return fail(RTMI_ERR_BAD_ARG);
+    }
+#ifndef RTMI_EXPERIMENTAL
+    if (tune.kernel == 2u) {
+        set_error("rtmi_scene_create: the queue-scheduled kernel (rtmi_tuning::kernel = 2) is an experiment that lost on every "
+                  "measured workload; it is only in libraries built with -DRTMI_EXPERIMENTAL");
+        return fail(RTMI_ERR_UNSUPPORTED);
+    }
+#else
     s->wf_enabled = s->accel == RTMI_ACCEL_BVH && n_objects > 0 && tune.kernel == 2u; // 0 / 1: round-based kernel
     if (s->wf_enabled) {
         if (tune.wf_block_lanes) s->wf_block = std::min(1024u, std::max(64u, (tune.wf_block_lanes / 64u) * 64u));
@@ -1574,6 +1478,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_wf_error), 16));
         HIP_TRY_S(hipMemset(s->d_wf_error, 0, 16));
     }
+#endif
 
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_counter), 16));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 64 * sizeof(unsigned long long)));
@@ -1584,7 +1489,6 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY_S(hipEventCreate(&s->ev0));
     HIP_TRY_S(hipEventCreate(&s->ev1));
-    HIP_TRY_S(hipEventCreate(&s->ev2));
 #undef HIP_TRY_S
     return RTMI_OK;
 }
@@ -1715,6 +1619,7 @@ extern "C" int rtmi_scene_get_launch_info(const rtmi_scene* s, rtmi_launch_info*
     out->lds_bytes = wf ? s->wf_lds_bytes : s->lds_bytes;
     out->scene_in_lds = s->big ? 0u : 1u;
     out->stack_depth = s->stack_depth;
+    out->whole_pixel_fallbacks = s->whole_pixel_fallbacks;
     return RTMI_OK;
 }
 
@@ -1753,7 +1658,13 @@ extern "C" int rtmi_scene_last_kernel_ms(rtmi_scene* s, float* ms_out) {
     }
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventSynchronize(s->ev1));
-    HIP_TRY(hipEventElapsedTime(ms_out, s->ev0, s->ev2)); // the trace kernel alone; the resolve pass follows it
+    float total = 0.0f; // the trace kernels alone, band by band; the resolve passes between them are not counted
+    for (uint32_t b = 0; b < s->n_bands_timed; ++b) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_trace[2u * b], s->ev_trace[2u * b + 1u]));
+        total += ms;
+    }
+    *ms_out = total;
     return check_watchdog(s);
 }
 

@@ -3,13 +3,14 @@
 // Replaces the worker fan-out of the reference's RayTracer::create (src/main.cc:586-731: one std::thread per core,
 // a shuffled queue of 8x8 tiles) and the per-frame drain of RayTracer::update (src/main.cc:733-774: ZeroMQ inproc
 // mailboxes, one message per pixel) by: one scene replica per device, the image plane sharded by interleaved row
-// blocks (block b -> device b mod n), ONE RCCL gather of the dense per-device slices over xGMI to devices[0], and a
-// small kernel that restores scanline order.  No exchange happens during rendering: pixels are independent and the
+// blocks (block b -> device b mod n), ONE RCCL gather of the dense per-device slices (float RGB and RGBA8 of a device
+// packed into one buffer, so that a frame is one ncclGather per rank) over xGMI to devices[0], and a small kernel that
+// restores scanline order.  No exchange happens during rendering: pixels are independent and the
 // draw streams are keyed by absolute (pixel, sample), so the frame is bit-identical for any n.
 //
 // Built on the single-device entry points (rtmi_scene_create / rtmi_render_row_blocks_device); librccl is opened
-// at run time, and only when n > 1: a host that already carries an RCCL (torch does) shares its copy, and a
-// single-GPU host never loads the 570 MB library.
+// at run time, and only when n > 1 (or when RTMI_FRAME_FORCE_RCCL asks for a one-rank communicator): a host that already
+// carries an RCCL (torch does) shares its copy, and a single-GPU host never loads the 570 MB library.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -66,18 +67,22 @@ RcclApi& rccl_api() {
     return api;
 }
 
-// gathered rows are rank-major ([rank][max_rows]); image row y sits at gathered row index[y]
-__global__ void __launch_bounds__(256) rtmi_deinterleave_kernel(const float* __restrict__ g_rgb, const uint32_t* __restrict__ g_rgba,
-                                                                const uint32_t* __restrict__ index, uint32_t W, uint32_t H,
+// The gathered buffer is rank-major: rank r's slice = [max_rows * W * 3 floats | max_rows * W RGBA8 words], `slice_words`
+// 32-bit words apart; image row y sits at row index[y] % max_rows of rank index[y] / max_rows.
+__global__ void __launch_bounds__(256) rtmi_deinterleave_kernel(const uint32_t* __restrict__ gathered, const uint32_t* __restrict__ index,
+                                                                uint32_t W, uint32_t H, uint32_t max_rows, size_t slice_words,
                                                                 float* __restrict__ rgb, uint32_t* __restrict__ rgba) {
     const uint32_t y = blockIdx.y;
     if (y >= H) return;
-    const size_t src = (size_t)index[y] * W, dst = (size_t)y * W;
+    const uint32_t r = index[y] / max_rows, lr = index[y] - r * max_rows;
+    const uint32_t* g_rgb = gathered + (size_t)r * slice_words + (size_t)lr * W * 3;
+    const uint32_t* g_rgba = gathered + (size_t)r * slice_words + (size_t)max_rows * W * 3 + (size_t)lr * W;
+    const size_t dst = (size_t)y * W;
     for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < W; x += gridDim.x * blockDim.x) {
-        rgba[dst + x] = g_rgba[src + x];
-        rgb[3 * (dst + x) + 0] = g_rgb[3 * (src + x) + 0];
-        rgb[3 * (dst + x) + 1] = g_rgb[3 * (src + x) + 1];
-        rgb[3 * (dst + x) + 2] = g_rgb[3 * (src + x) + 2];
+        rgba[dst + x] = g_rgba[x];
+        rgb[3 * (dst + x) + 0] = __uint_as_float(g_rgb[3 * x + 0]);
+        rgb[3 * (dst + x) + 1] = __uint_as_float(g_rgb[3 * x + 1]);
+        rgb[3 * (dst + x) + 2] = __uint_as_float(g_rgb[3 * x + 2]);
     }
 }
 
@@ -90,16 +95,17 @@ struct Shard {
 struct rtmi_frame {
     uint32_t n = 0, W = 0, H = 0, block_rows = 8, max_rows = 0;
     bool rehearsal = false; // test hook: devices may repeat, slices are gathered with copies instead of RCCL
+    bool force_rccl = false; // test hook: a communicator and the gather even for n == 1 (rank 0 gathers from itself)
+    size_t slice_words = 0;  // 32-bit words per slice: max_rows * W * (3 + 1)
     std::vector<int> devices;
     std::vector<rtmi_scene*> scenes;
     std::vector<hipStream_t> streams;
-    std::vector<float*> d_rgb_slice;      // per device: max_rows * W * 3
-    std::vector<uint32_t*> d_rgba_slice;  // per device: max_rows * W
+    std::vector<uint32_t*> d_slice;       // per device: [max_rows * W * 3 floats | max_rows * W RGBA8]
     std::vector<Shard> shards;
-    std::vector<ncclComm_t> comms;        // empty when n == 1
+    std::vector<ncclComm_t> comms;        // empty when no communicator exists (n == 1 without RTMI_FRAME_FORCE_RCCL)
     // on devices[0]
-    float* d_rgb_gather = nullptr;        // n * max_rows * W * 3 (n > 1; otherwise the slice itself)
-    uint32_t* d_rgba_gather = nullptr;
+    uint32_t* d_gather = nullptr;         // n * slice_words (when a gather happens; otherwise the slice itself)
+    bool own_gather = false;
     float* d_rgb_frame = nullptr;         // H * W * 3, scanline order
     uint32_t* d_rgba_frame = nullptr;
     uint32_t* d_index = nullptr;          // H
@@ -147,16 +153,12 @@ void free_frame(rtmi_frame* f) {
     for (uint32_t i = 0; i < f->devices.size(); ++i) {
         (void)hipSetDevice(f->devices[i]);
         if (i < f->scenes.size() && f->scenes[i]) rtmi_scene_destroy(f->scenes[i]);
-        if (i < f->d_rgb_slice.size()) (void)hipFree(f->d_rgb_slice[i]);
-        if (i < f->d_rgba_slice.size()) (void)hipFree(f->d_rgba_slice[i]);
+        if (i < f->d_slice.size()) (void)hipFree(f->d_slice[i]);
         if (i < f->streams.size() && f->streams[i]) (void)hipStreamDestroy(f->streams[i]);
     }
     if (!f->devices.empty()) {
         (void)hipSetDevice(f->devices[0]);
-        if (f->n > 1) {
-            (void)hipFree(f->d_rgb_gather);
-            (void)hipFree(f->d_rgba_gather);
-        }
+        if (f->own_gather) (void)hipFree(f->d_gather);
         (void)hipFree(f->d_rgb_frame);
         (void)hipFree(f->d_rgba_frame);
         (void)hipFree(f->d_index);
@@ -175,7 +177,8 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
     opt.device = -1;
     if (options) std::memcpy(&opt, options, std::min<size_t>(sizeof(opt), options->struct_size));
     opt.struct_size = sizeof(opt);
-    const bool rehearsal = (opt.reserved[0] & 1u) != 0u; // RTMI_FRAME_REHEARSAL
+    const bool rehearsal = (opt.reserved[0] & RTMI_FRAME_REHEARSAL) != 0u;
+    const bool force_rccl = (opt.reserved[0] & RTMI_FRAME_FORCE_RCCL) != 0u && !rehearsal;
     for (uint32_t i = 0; i < n; ++i) {
         if (devices[i] < 0 || devices[i] >= n_visible) {
             set_error("rtmi_frame_create: device ordinal outside the visible devices");
@@ -195,14 +198,14 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
     }
     f->n = n;
     f->rehearsal = rehearsal;
+    f->force_rccl = force_rccl;
     f->W = camera->img_width;
     f->H = camera->img_height;
     f->block_rows = block_rows ? block_rows : 8u;
     f->devices.assign(devices, devices + n);
     f->scenes.assign(n, nullptr);
     f->streams.assign(n, nullptr);
-    f->d_rgb_slice.assign(n, nullptr);
-    f->d_rgba_slice.assign(n, nullptr);
+    f->d_slice.assign(n, nullptr);
     f->shards.assign(n, Shard{});
 
     // interleaved row blocks: block b -> device b mod n; every device renders into a dense slice of max_rows rows
@@ -221,17 +224,17 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
         index[y] = r * f->max_rows + k * B + (y - b * B);
     }
 
-    const size_t slice_px = (size_t)std::max(1u, f->max_rows) * std::max(1u, W);
+    f->max_rows = std::max(1u, f->max_rows);
+    const size_t slice_px = (size_t)f->max_rows * std::max(1u, W);
+    f->slice_words = slice_px * 4;
     for (uint32_t i = 0; i < n; ++i) {
         HIPF(hipSetDevice(devices[i]));
         opt.device = devices[i];
         const int rc = rtmi_scene_create(camera, objects, n_objects, materials, n_materials, &opt, &f->scenes[i]);
         if (rc != RTMI_OK) return rc;
         HIPF(hipStreamCreateWithFlags(&f->streams[i], hipStreamNonBlocking));
-        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgb_slice[i]), slice_px * 3 * sizeof(float)));
-        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgba_slice[i]), slice_px * sizeof(uint32_t)));
-        HIPF(hipMemset(f->d_rgb_slice[i], 0, slice_px * 3 * sizeof(float)));
-        HIPF(hipMemset(f->d_rgba_slice[i], 0, slice_px * sizeof(uint32_t)));
+        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_slice[i]), f->slice_words * sizeof(uint32_t)));
+        HIPF(hipMemset(f->d_slice[i], 0, f->slice_words * sizeof(uint32_t)));
     }
     HIPF(hipSetDevice(devices[0]));
     const size_t frame_px = (size_t)std::max(1u, H) * std::max(1u, W);
@@ -241,11 +244,13 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
     if (H) HIPF(hipMemcpy(f->d_index, index.data(), H * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPF(hipEventCreate(&f->ev_g0));
     HIPF(hipEventCreate(&f->ev_g1));
-    if (n > 1) {
-        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgb_gather), slice_px * n * 3 * sizeof(float)));
-        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_rgba_gather), slice_px * n * sizeof(uint32_t)));
+    if (n > 1 || force_rccl) {
+        HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_gather), f->slice_words * n * sizeof(uint32_t)));
+        f->own_gather = true;
+    } else {
+        f->d_gather = f->d_slice[0];
     }
-    if (n > 1 && !rehearsal) {
+    if ((n > 1 && !rehearsal) || force_rccl) {
         RcclApi& api = rccl_api();
         if (!api.error.empty() || !api.Gather) {
             set_error("rtmi_frame_create: " + (api.error.empty() ? std::string("librccl unusable") : api.error));
@@ -253,9 +258,6 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
         }
         f->comms.assign(n, nullptr);
         NCCLF(api.CommInitAll(f->comms.data(), (int)n, f->devices.data()));
-    } else if (n == 1) {
-        f->d_rgb_gather = f->d_rgb_slice[0];
-        f->d_rgba_gather = f->d_rgba_slice[0];
     }
     return RTMI_OK;
 }
@@ -268,38 +270,33 @@ int frame_render_impl(rtmi_frame* f, uint64_t seed) {
         const Shard& sh = f->shards[i];
         if (!sh.n_blocks) continue;
         const int rc = rtmi_render_row_blocks_device(f->scenes[i], sh.y_first, f->block_rows, n, sh.n_blocks, seed,
-                                                     f->d_rgb_slice[i], f->d_rgba_slice[i], f->streams[i]);
+                                                     f->d_slice[i], f->d_slice[i] + (size_t)f->max_rows * W * 3, f->streams[i]);
         if (rc != RTMI_OK) return rc;
     }
     HIPF(hipSetDevice(f->devices[0]));
     HIPF(hipEventRecord(f->ev_g0, f->streams[0]));
     if (n > 1 && f->rehearsal) {
         // test hook: the same plan with plain copies, so that one box can check the shard and scanline-order arithmetic
-        const size_t slice_px = (size_t)f->max_rows * W;
         for (uint32_t i = 0; i < n; ++i) {
             HIPF(hipSetDevice(f->devices[i]));
             HIPF(hipStreamSynchronize(f->streams[i]));
-            HIPF(hipMemcpyAsync(f->d_rgb_gather + (size_t)i * slice_px * 3, f->d_rgb_slice[i], slice_px * 3 * sizeof(float),
-                                hipMemcpyDeviceToDevice, f->streams[0]));
-            HIPF(hipMemcpyAsync(f->d_rgba_gather + (size_t)i * slice_px, f->d_rgba_slice[i], slice_px * sizeof(uint32_t),
+            HIPF(hipMemcpyAsync(f->d_gather + (size_t)i * f->slice_words, f->d_slice[i], f->slice_words * sizeof(uint32_t),
                                 hipMemcpyDeviceToDevice, f->streams[0]));
         }
         HIPF(hipSetDevice(f->devices[0]));
-    } else if (n > 1) {
+    } else if (!f->comms.empty()) {
         // ONE gather of the dense slices to devices[0]: every rank's call sits in one group, on its own stream, behind its
-        // own kernels
+        // own kernels (a slice is float RGB followed by RGBA8, moved as 32-bit words)
         RcclApi& api = rccl_api();
-        const size_t slice_px = (size_t)f->max_rows * W;
         NCCLF(api.GroupStart());
         for (uint32_t i = 0; i < n; ++i) {
-            NCCLF(api.Gather(f->d_rgb_slice[i], f->d_rgb_gather, slice_px * 3, ncclFloat32, 0, f->comms[i], f->streams[i]));
-            NCCLF(api.Gather(f->d_rgba_slice[i], f->d_rgba_gather, slice_px, ncclUint32, 0, f->comms[i], f->streams[i]));
+            NCCLF(api.Gather(f->d_slice[i], f->d_gather, f->slice_words, ncclUint32, 0, f->comms[i], f->streams[i]));
         }
         NCCLF(api.GroupEnd());
         HIPF(hipSetDevice(f->devices[0]));
     }
     rtmi_deinterleave_kernel<<<dim3((W + 255u) / 256u, H), dim3(256), 0, f->streams[0]>>>(
-        f->d_rgb_gather, f->d_rgba_gather, f->d_index, W, H, f->d_rgb_frame, f->d_rgba_frame);
+        f->d_gather, f->d_index, W, H, f->max_rows, f->slice_words, f->d_rgb_frame, f->d_rgba_frame);
     HIPF(hipGetLastError());
     HIPF(hipEventRecord(f->ev_g1, f->streams[0]));
     for (uint32_t i = 0; i < n; ++i) {
@@ -403,6 +400,15 @@ extern "C" int rtmi_frame_get_timing(const rtmi_frame* f, rtmi_frame_timing* out
         return RTMI_ERR_BAD_ARG;
     }
     *out = f->timing;
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_frame_get_scene(rtmi_frame* f, uint32_t index, rtmi_scene** scene_out) {
+    if (!f || !scene_out || index >= f->scenes.size()) {
+        try { set_error("rtmi_frame_get_scene: null argument or index outside the device list"); } catch (...) {}
+        return RTMI_ERR_BAD_ARG;
+    }
+    *scene_out = f->scenes[index];
     return RTMI_OK;
 }
 

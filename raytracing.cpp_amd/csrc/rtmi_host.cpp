@@ -70,7 +70,13 @@ private:
 using namespace rtmi;
 
 extern "C" const char* rtmi_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char* rtmi_version(void) { return "rtmi 0.2 (gfx950)"; }
+extern "C" const char* rtmi_version(void) {
+#ifdef RTMI_EXPERIMENTAL
+    return "rtmi 0.3 (gfx950, experimental: + queue-scheduled kernel)";
+#else
+    return "rtmi 0.3 (gfx950)";
+#endif
+}
 
 // RayTracingCore::default_setup camera block, reference core.cc:171-216.
 extern "C" int rtmi_camera_setup(const rtmi_camera_params* cp, rtmi_camera* out) {

@@ -18,6 +18,16 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kMaxPadClasses = 4;
 constexpr uint32_t kMaxLeafSize = 4;
 
+// The counter streams are keyed by a bijective mix of the caller's 64-bit seed (the finaliser of splitmix64, Steele,
+// Lea & Flood, OOPSLA'14): seeds that differ in one bit, or only in their high word, give unrelated key words
+// (oracle/rt_oracle.c: orc_mix_seed).
+inline uint64_t mix_seed(uint64_t seed) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return kLeafBit | (count << 24) | first; }
 
 // Host-built acceleration structure.  Slots are the spheres in leaf order; slot_object[i] is the index of the

@@ -55,15 +55,6 @@ struct RtmiLaunch {
     // the whole pixel and sums in registers.
     uint32_t chunk, n_chunks;
     float4* sample_buf;
-    // path deferral (needs the sample buffer): a path that turns out to bounce INSIDE an opaque sphere (back-face hit
-    // on a Lambertian/Metallic material -- fp32 self-intersection of the ground sphere traps 3 % of the samples for all
-    // 50 bounces, 39 % of all segments) is written to a compacted queue and finished by a second launch of this kernel
-    // (mode 1) whose lanes all walk such paths: 2-3 BVH steps per segment instead of idling next to 13-step walks.
-    // A scheduling decision only: both launches run the same arithmetic on the same (pixel, sample, draw) stream.
-    uint4* defer_buf;       // [defer_cap] records of 5 x uint4
-    uint32_t* defer_count;  // records appended (may overshoot defer_cap; clamp)
-    uint32_t defer_cap;
-    uint32_t mode;          // 0: primary launch, 1: drain launch (work items are queue records)
     uint32_t wait_thresh;     // leave the traversal loop when this many lanes of a wave wait for shading
     uint64_t seed;
     float* out_rgb;
@@ -286,10 +277,13 @@ DEV void pcg4d(uint32_t x, uint32_t y, uint32_t z, uint32_t w, Blk& r) {
     x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
     r.w0 = x; r.w1 = y; r.w2 = z; r.w3 = w;
 }
-// block `blk` of the stream (seed, pixel, sample)
+// block `blk` of the stream (seed, pixel, sample).  `seed` arrives pre-mixed (rtmi::mix_seed on the host, a bijection of
+// the caller's 64-bit seed): its two halves are two key words that look random whatever the structure of the caller's
+// seeds, and neither of them is combined with the sample index -- round 2 fed `sample ^ seed_hi`, so that two seeds
+// differing in the high word by less than spp drew the same paths per pixel in another order.
 DEV void rng4x32(uint32_t blk, uint32_t sample, uint32_t pixel, uint64_t seed, Blk& r) {
 #if RTMI_RNG == 0
-    pcg4d(blk, sample ^ (uint32_t)(seed >> 32), pixel, (uint32_t)seed, r);
+    pcg4d(blk ^ (uint32_t)(seed >> 32), sample, pixel, (uint32_t)seed, r);
 #else
     philox4x32<RTMI_RNG>(blk, sample, pixel, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
 #endif

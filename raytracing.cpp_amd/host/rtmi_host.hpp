@@ -474,10 +474,13 @@ struct RayTracingCore {
 
     // device side (owned): created by default_setup / setup, released by the destructor
     std::shared_ptr<rtmi_scene> rts_gpu_scene;
-    // more GPUs of the node (optional, attach_devices): one scene replica per listed device for workers that pull row
-    // blocks from a shared queue (the reference's N workers, main.cc:608-712), and one rtmi_frame for whole frames
-    // (interleaved row-block shards + one RCCL gather inside the library)
-    std::vector<std::shared_ptr<rtmi_scene>> rts_gpu_replicas;
+    // more GPUs of the node (optional, attach_devices): one rtmi_frame for whole frames (interleaved row-block shards + one
+    // RCCL gather inside the library); its per-device scene replicas also serve workers that pull row blocks from a
+    // shared queue (the reference's N workers, main.cc:608-712) -- one scene per device, borrowed from the frame
+    // (rtmi_frame_get_scene), not a second copy.  Footprint per device: BVH + strips + the sample records of the largest
+    // call so far (16 B per sample, capped by rtmi_tuning::sample_buf_mb).  raytrace_frame and raytrace_rows_on must not
+    // run at the same time.
+    std::vector<rtmi_scene*> rts_gpu_replicas; // owned by rts_gpu_frame
     std::shared_ptr<rtmi_frame> rts_gpu_frame;
     rtmi_camera rts_camera_pod{}; // the 14 fields above as the C-ABI record
 
@@ -532,26 +535,21 @@ struct RayTracingCore {
     // Replicates the scene on `devices` (HIP ordinals).  Returns an rtmi_status; nothing is attached on failure.
     int attach_devices(const std::vector<int32_t>& devices, uint32_t block_rows = 8,
                        const rtmi_scene_options* options = nullptr) {
-        std::vector<std::shared_ptr<rtmi_scene>> replicas;
-        rtmi_scene_options opt{};
-        if (options) opt = *options;
-        opt.struct_size = sizeof(opt);
         const auto* objs = reinterpret_cast<const rtmi_object*>(rts_world.data());
         const auto* mats = reinterpret_cast<const rtmi_material*>(rts_materials.data());
         const auto n_objs = static_cast<uint32_t>(rts_world.size()), n_mats = static_cast<uint32_t>(rts_materials.size());
-        for (const int32_t d : devices) {
-            opt.device = d;
-            rtmi_scene* scene = nullptr;
-            const int rc = rtmi_scene_create(&rts_camera_pod, objs, n_objs, mats, n_mats, &opt, &scene);
-            if (rc != RTMI_OK) return rc;
-            replicas.emplace_back(scene, rtmi_scene_destroy);
-        }
         rtmi_frame* frame = nullptr;
-        const int rc = rtmi_frame_create(&rts_camera_pod, objs, n_objs, mats, n_mats, options, devices.data(),
-                                         static_cast<uint32_t>(devices.size()), block_rows, &frame);
+        int rc = rtmi_frame_create(&rts_camera_pod, objs, n_objs, mats, n_mats, options, devices.data(),
+                                   static_cast<uint32_t>(devices.size()), block_rows, &frame);
         if (rc != RTMI_OK) return rc;
+        std::shared_ptr<rtmi_frame> holder(frame, rtmi_frame_destroy);
+        std::vector<rtmi_scene*> replicas(devices.size(), nullptr);
+        for (uint32_t i = 0; i < devices.size(); ++i) {
+            rc = rtmi_frame_get_scene(frame, i, &replicas[i]);
+            if (rc != RTMI_OK) return rc;
+        }
         rts_gpu_replicas = std::move(replicas);
-        rts_gpu_frame = std::shared_ptr<rtmi_frame>(frame, rtmi_frame_destroy);
+        rts_gpu_frame = std::move(holder);
         return RTMI_OK;
     }
 
@@ -565,7 +563,7 @@ struct RayTracingCore {
     int raytrace_rows_on(size_t replica, uint32_t y0, uint32_t y1, uint64_t seed, RGBAColor* rgba,
                          float* rgb_linear = nullptr) const noexcept {
         if (replica >= rts_gpu_replicas.size()) return RTMI_ERR_BAD_ARG;
-        return rtmi_render_rows(rts_gpu_replicas[replica].get(), y0, y1, seed, rgb_linear, reinterpret_cast<uint32_t*>(rgba));
+        return rtmi_render_rows(rts_gpu_replicas[replica], y0, y1, seed, rgb_linear, reinterpret_cast<uint32_t*>(rgba));
     }
 
     // Replaces the per-pixel loop over RayTracingCore::raytrace_pixel (core.cc:259-265, called from

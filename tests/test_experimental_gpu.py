@@ -1,0 +1,126 @@
+"""Tests of the -DRTMI_EXPERIMENTAL build (librtmi_exp.so): the queue-scheduled kernel of round 2 (rtmi_wavefront.hip),
+which lost to the round-based kernel on every measured workload and is therefore not in the shipped
+library.  Skipped unless that library has been built:
+
+    python -c "import rtmi_loader; rtmi_loader.load().build_library(experimental=True)"
+"""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN, ROOT
+from tests.scenes import three_spheres, three_spheres_camera
+from tests.test_gpu_parity import _assert_frames_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def xpkg():
+    """A second instance of the package module bound to librtmi_exp.so."""
+    pkg_dir = os.path.join(ROOT, "raytracing.cpp_amd")
+    if not os.path.exists(os.path.join(pkg_dir, "librtmi_exp.so")):
+        pytest.skip("librtmi_exp.so not built (build_library(experimental=True))")
+    name = "raytracing_cpp_amd_exp"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(pkg_dir, "__init__.py"),
+                                                  submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    mod.LIB_PATH = mod.EXP_LIB_PATH
+    assert mod.experimental()
+    return mod
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("marked gpu but no GPU is visible: the product has no CPU fallback")
+    return torch
+
+
+@pytest.mark.parametrize("tuning", [dict(kernel=2), dict(kernel=2, wf_block_lanes=512, wf_slots=320, wf_refill=8),
+                                    dict(kernel=2, wf_refill=56, blocks_per_cu=1), dict(kernel=2, force_hbm_scene=1)])
+def test_queue_scheduled_kernel_matches_oracle(xpkg, ob, rtow, gpu, tuning):
+    """rtmi_tuning::kernel = 2 (rtmi_wavefront.hip: path slots and rings in LDS, waves take homogeneous batches): same
+    draw streams, same arithmetic -- the oracle's frame bit for bit, the oracle's work counters, for LDS- and
+    HBM-resident scenes, deep bounces, depth limits 0 and 1, ragged images, sharded row blocks and banded calls."""
+    torch, pkg = gpu, xpkg
+    kw = dict(image_width=144, samples_per_pixel=12, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    W, H = cam.img_width, cam.img_height
+    want, want8 = ob.render_rect_counter(ocam, *rtow, 71, 0, 0, W, H, nthreads=8)
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=tuning) as s:
+        rgb, rgba = s.render_rows(0, H, 71)
+        st = s.stats()
+        part, _ = s.render_rows(5, 23, 71)
+        # sharded row blocks through the device-pointer entry
+        dev = torch.device("cuda", 0)
+        plan = pkg.RowShardPlan(H, 8, 3)
+        parts = []
+        for r in range(3):
+            y_first, n_blocks, rows = plan.shard(r)
+            buf = torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev)
+            s.render_row_blocks_device(y_first, 8, 3, n_blocks, 71, buf.data_ptr(), 0, torch.cuda.current_stream(dev).cuda_stream)
+            parts.append(buf)
+        torch.cuda.synchronize()
+        s.last_kernel_ms()  # also reads the watchdog word
+        frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev)).cpu().numpy()
+    _assert_frames_equal(rgb, want)
+    assert np.array_equal(rgba, want8)
+    _assert_frames_equal(part, want[5:23])
+    _assert_frames_equal(frame, want)
+    assert st["samples"] == H * W * 12
+    # deep bounces (config 5 shape) and a banded call
+    g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
+    ccam = pkg.camera_setup(pkg.camera_params(**json.loads(str(g["camera"]))))
+    with pkg.Scene(ccam, g["objects"], g["materials"], accel=pkg.ACCEL_BVH, tuning=dict(tuning, sample_buf_mb=1)) as s:
+        crgb, crgba = s.render_rows(0, ccam.img_height, int(g["seed"]))
+    _assert_frames_equal(crgb, g["rgb"])
+    assert np.array_equal(crgba, g["rgba"])
+    # depth limits 0 and 1, ragged sizes
+    objs, mats = three_spheres()
+    for (w, aspect, spp, depth) in ((33, 1.0, 5, 0), (65, 3.0, 9, 1), (100, 16.0 / 9.0, 17, 7)):
+        k3 = dict(three_spheres_camera(), image_width=w, aspect_ratio=aspect, samples_per_pixel=spp, max_depth=depth)
+        c3, o3 = pkg.camera_setup(pkg.camera_params(**k3)), ob.camera_setup(ob.camera_params(**k3))
+        w3, w38 = ob.render_rect_counter(o3, objs, mats, 4, 0, 0, c3.img_width, c3.img_height)
+        with pkg.Scene(c3, objs, mats, accel=pkg.ACCEL_BVH, tuning=tuning) as s:
+            r3, r38 = s.render_rows(0, c3.img_height, 4)
+        _assert_frames_equal(r3, w3)
+        assert np.array_equal(r38, w38)
+
+
+def test_queue_scheduled_kernel_statistics(xpkg, ob, rtow, gpu):
+    """Work counters of the queue-scheduled kernel equal the oracle's instrumented walk of the same tree."""
+    pkg = xpkg
+    kw = dict(image_width=96, samples_per_pixel=8, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    bvh = pkg.bvh_build(rtow[0])
+    obvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
+    _, _, ctr = ob.render_rect_counter(ocam, *rtow, 3, 0, 0, ocam.img_width, ocam.img_height, nthreads=8, counters=True, bvh=obvh)
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=dict(kernel=2)) as s:
+        s.render_rows(0, cam.img_height, 3)
+        st = s.stats()
+    assert st["samples"] == ctr["samples"] and st["segments"] == ctr["segments"]
+    # v_rcp_f32 in the (conservative) slab test against the oracle's true division: visit counts differ in the last digits
+    for k in ("sphere_tests", "node_tests"):
+        assert abs(st[k] - ctr[k]) <= 1e-3 * ctr[k], (k, st[k], ctr[k])
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=dict(kernel=1)) as s:
+        s.render_rows(0, cam.img_height, 3)
+        assert s.stats() == st  # the two kernels walk the same tree with the same arithmetic
+
+
+def test_queue_scheduled_kernel_equals_linear_scan_on_generated_worlds(xpkg, gpu):
+    """BVH walk of the queue-scheduled kernel == the linear scan on a few generated worlds (the shipped kernel's 36-world
+    test is tests/test_gpu_parity.py::test_bvh_walk_equals_linear_scan_on_generated_worlds)."""
+    from tests.test_gpu_parity import _bvh_equals_scan
+    pkg = xpkg
+    for i in range(4):
+        objs, mats = pkg.make_world_spheres(1000 + i)
+        cam = pkg.camera_setup(pkg.camera_params(image_width=160, samples_per_pixel=6, max_depth=50))
+        assert _bvh_equals_scan(pkg, cam, objs, mats, 77 + i, tunings=(dict(kernel=2),)) == 0

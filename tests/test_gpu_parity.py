@@ -56,27 +56,25 @@ def gpu(pkg):
 # ---------------------------------------------------------------------------------------------------------------
 # golden fixtures and oracle parity at oracle-sized problems
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("defer", [0, 1])  # 0 = auto: launches this small keep the deferred-path queue off
-def test_golden_rtow_counter_frame(pkg, gpu, defer):
+def test_golden_rtow_counter_frame(pkg, gpu):
     g = np.load(os.path.join(GOLDEN, "rtow_counter_128x72x16.npz"))
     sc = np.load(os.path.join(GOLDEN, "rtow_scene_seed12345.npz"))
     cp = json.loads(str(g["camera"]))
     cam = pkg.camera_setup(pkg.camera_params(**cp))
     for accel, _ in _both(pkg):
-        with pkg.Scene(cam, sc["objects"], sc["materials"], accel=accel, tuning=dict(defer_mode=defer)) as s:
+        with pkg.Scene(cam, sc["objects"], sc["materials"], accel=accel) as s:
             rgb, rgba = s.render_rows(0, cam.img_height, int(g["seed"]))
         _assert_frames_equal(rgb, g["rgb"])
         assert np.array_equal(rgba, g["rgba"])
 
 
-@pytest.mark.parametrize("defer", [0, 1])
-def test_golden_cornell_deep_bounce(pkg, gpu, defer):
+def test_golden_cornell_deep_bounce(pkg, gpu):
     """config 5 shape: enclosed box, 200 bounces."""
     g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
     cp = json.loads(str(g["camera"]))
     cam = pkg.camera_setup(pkg.camera_params(**cp))
     for accel, _ in _both(pkg):
-        with pkg.Scene(cam, g["objects"], g["materials"], accel=accel, tuning=dict(defer_mode=defer)) as s:
+        with pkg.Scene(cam, g["objects"], g["materials"], accel=accel) as s:
             rgb, rgba = s.render_rows(0, cam.img_height, int(g["seed"]))
         _assert_frames_equal(rgb, g["rgb"])
         assert np.array_equal(rgba, g["rgba"])
@@ -157,21 +155,23 @@ def test_launch_info_reports_what_the_tuning_resolved_to(pkg, rtow, gpu):
     with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(force_hbm_scene=1, block_lanes=512)) as s:
         li2 = s.launch_info()
     assert li2["scene_in_lds"] == 0 and li2["block_lanes"] == 512 and li2["lds_bytes"] < li["lds_bytes"]
-    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(kernel=2)) as s:
-        li3 = s.launch_info()
-    assert li3["kernel"] == 2 and li3["block_lanes"] == 1024
+    # the queue-scheduled kernel of round 2 is not in the shipped library (tests/test_experimental_gpu.py covers the
+    # -DRTMI_EXPERIMENTAL build): asking for it fails loudly instead of silently running something else
+    with pytest.raises(pkg.RtmiError) as e:
+        pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(kernel=2))
+    assert e.value.code == pkg.RTMI_ERR_UNSUPPORTED and not pkg.experimental()
     with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(blocks_per_cu=1)) as s:
         assert s.launch_info()["blocks_per_cu"] == 1
 
 
 def test_scheduling_knobs_do_not_change_the_image(pkg, ob, rtow, gpu):
-    """Sample-chunk work items, the deferred-path queue (also when it overflows), launch geometry and the traversal
-    exit threshold are scheduling decisions: every combination yields the oracle's frame bit for bit."""
+    """Sample-chunk work items, launch geometry and the traversal exit threshold are scheduling decisions: every
+    combination yields the oracle's frame bit for bit."""
     kw = dict(image_width=128, samples_per_pixel=96, max_depth=50)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
     want, want8 = ob.render_rect_counter(ocam, *rtow, 44, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
-    for env in (dict(chunk_samples=-1), dict(chunk_samples=16, defer_mode=-1), dict(chunk_samples=16, defer_mode=1),
-                dict(chunk_samples=32, defer_mode=1, defer_cap=64), dict(chunk_samples=40, block_lanes=256, wait_thresh=20),
+    for env in (dict(chunk_samples=-1), dict(chunk_samples=16), dict(chunk_samples=3, block_lanes=640),
+                dict(chunk_samples=32, sample_buf_mb=1), dict(chunk_samples=40, block_lanes=256, wait_thresh=20),
                 dict(blocks_per_cu=1, wait_thresh=64, top_down=1)):
         with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=env) as s:
             rgb, rgba = s.render_rows(0, cam.img_height, 44)
@@ -283,6 +283,98 @@ def test_degenerate_scenes(pkg, ob, gpu):
     _assert_frames_equal(rgb, want)
 
 
+def _closed_box():
+    """The camera sits inside one big Lambertian sphere (every ray hits it from the inside and scatters inwards), a glass
+    sphere floats in it: no opening, every path runs until its bounce limit."""
+    return arrays([((0.0, 0.0, 0.0), 10.0, (0, (0.8, 0.8, 0.8, 0.0))), ((0.5, -1.0, 0.0), 1.0, (2, (1.5, 0.0, 0.0, 0.0))),
+                   ((-2.0, 1.0, -1.0), 1.5, (0, (0.6, 0.7, 0.9, 0.0)))])
+
+
+def test_inputs_the_reference_api_admits(pkg, ob, gpu):
+    """inputs the reference's API accepts that no other test feeds the kernel -- a negative radius (the
+    hollow-glass idiom: (p - C) / R flips the normal, object.defs.cc:62-63), radius 0, refraction index exactly 1, fuzz 0
+    and fuzz above 1 (Metallic clamps at construction, material.defs.hpp:73; the raw record is passed as is on both
+    sides), albedo above 1, center_dist_treshold = 3 (no grid sphere survives `3 > 3`, core.cc:130), lookfrom == lookat
+    (a NaN camera), samples_per_pixel = 65535, max_depth = 65535 -- both accel paths, both memory layouts, frames equal
+    to the oracle's (NaN = NaN)."""
+    lam, glass = (0, (0.5, 0.5, 0.5, 0.0)), (2, (1.5, 0.0, 0.0, 0.0))
+    ground = ((0.0, -100.5, 0.0), 100.0, lam)
+    worlds = {
+        "hollow glass": [ground, ((0.0, 0.0, -1.0), 0.5, glass), ((0.0, 0.0, -1.0), -0.45, glass),
+                         ((1.1, 0.0, -1.0), -0.5, (0, (0.8, 0.3, 0.3, 0.0))), ((-1.1, 0.0, -1.0), -0.5, (1, (0.8, 0.8, 0.8, 0.3)))],
+        "radius 0": [ground, ((0.0, 0.0, -1.0), 0.0, lam), ((0.3, 0.1, -1.0), 0.0, glass), ((-0.5, 0.0, -1.0), 0.5, lam)],
+        "ri 1, fuzz 0 / 1 / 1.6, albedo > 1": [ground, ((0.0, 0.0, -1.0), 0.5, (2, (1.0, 0.0, 0.0, 0.0))),
+                                               ((1.0, 0.0, -1.0), 0.5, (1, (0.9, 0.9, 0.9, 0.0))),
+                                               ((-1.0, 0.0, -1.0), 0.5, (1, (0.9, 0.6, 0.2, 1.0))),
+                                               ((-2.0, 0.0, -1.5), 0.5, (1, (0.7, 0.7, 0.9, 1.6))),
+                                               ((2.0, 0.0, -1.5), 0.5, (0, (1.7, 1.2, 3.0, 0.0)))],
+    }
+    kw = dict(three_spheres_camera(), image_width=64, aspect_ratio=16.0 / 9.0, samples_per_pixel=24, max_depth=12)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    for name, spec in worlds.items():
+        objs, mats = arrays(spec)
+        want, want8 = ob.render_rect_counter(ocam, objs, mats, 31, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
+        assert np.isfinite(want).any(), name
+        for accel, _ in _both(pkg):
+            for tun in (None, dict(force_hbm_scene=1)):
+                with pkg.Scene(cam, objs, mats, accel=accel, tuning=tun) as s:
+                    rgb, rgba = s.render_rows(0, cam.img_height, 31)
+                _assert_frames_equal(rgb, want)
+                assert np.array_equal(rgba, want8), (name, accel, tun)
+    # center_dist_treshold = 3: glm's vec3::length() is the component count, so `3 > 3` drops every grid sphere
+    objs, mats = pkg.make_world_spheres(12345, wd=pkg.world_def(center_dist_treshold=3.0))
+    oobjs, omats = ob.make_world_spheres(12345, wd=ob.world_def(center_dist_treshold=3.0))
+    assert len(objs) == 4 and objs.tobytes() == oobjs.tobytes() and mats.tobytes() == omats.tobytes()
+    objs29, _ = pkg.make_world_spheres(12345, wd=pkg.world_def(center_dist_treshold=2.9))
+    assert len(objs29) == 488
+    # lookfrom == lookat: normalize(0) is NaN, every ray is NaN, every pixel is NaN on both sides (black in RGBA8)
+    kwn = dict(image_width=24, samples_per_pixel=3, max_depth=5, lookfrom=(1.0, 2.0, 3.0), lookat=(1.0, 2.0, 3.0))
+    camn, ocamn = pkg.camera_setup(pkg.camera_params(**kwn)), ob.camera_setup(ob.camera_params(**kwn))
+    objs, mats = arrays(worlds["hollow glass"])
+    want, want8 = ob.render_rect_counter(ocamn, objs, mats, 5, 0, 0, ocamn.img_width, ocamn.img_height)
+    assert np.isnan(want).all()
+    for accel, _ in _both(pkg):
+        with pkg.Scene(camn, objs, mats, accel=accel) as s:
+            rgb, rgba = s.render_rows(0, camn.img_height, 5)
+        _assert_frames_equal(rgb, want)
+        assert np.array_equal(rgba, want8)
+    # samples_per_pixel at the u16 limit on a 2 x 2 image (sample indices 0 .. 65534, one chunked and one whole-pixel launch)
+    kws = dict(three_spheres_camera(), image_width=2, aspect_ratio=1.0, samples_per_pixel=65535, max_depth=6)
+    cams, ocams = pkg.camera_setup(pkg.camera_params(**kws)), ob.camera_setup(ob.camera_params(**kws))
+    objs, mats = three_spheres()
+    want, want8 = ob.render_rect_counter(ocams, objs, mats, 77, 0, 0, 2, 2, nthreads=4)
+    for accel, _ in _both(pkg):
+        for tun in (None, dict(chunk_samples=-1)):
+            with pkg.Scene(cams, objs, mats, accel=accel, tuning=tun) as s:
+                rgb, rgba = s.render_rows(0, 2, 77)
+            _assert_frames_equal(rgb, want)
+            assert np.array_equal(rgba, want8)
+    # max_depth at the u16 limit inside a closed sphere: paths bounce thousands of times (fp32 self-intersection lets one
+    # leak out to the sky every ~1000 bounces, so none reaches 65535), a lane's attenuation chain can be 65535 entries
+    # long and the persistent grid shrinks to what 4 GiB of strips allow
+    objs, mats = _closed_box()
+    kwd = dict(aspect_ratio=1.0, image_width=2, samples_per_pixel=2, max_depth=65535, vertical_fov=60.0, defocus_angle=0.0,
+               focus_distance=1.0, lookfrom=(0.0, 0.0, 3.0), lookat=(0.0, 0.0, 0.0), world_up=(0.0, 1.0, 0.0))
+    camd, ocamd = pkg.camera_setup(pkg.camera_params(**kwd)), ob.camera_setup(ob.camera_params(**kwd))
+    want, want8, ctr = ob.render_rect_counter(ocamd, objs, mats, 3, 0, 0, 2, 2, nthreads=4, counters=True)
+    assert ctr["segments"] > 8 * 500
+    for accel, tun in ((pkg.ACCEL_BVH, None), (pkg.ACCEL_BRUTE, None), (pkg.ACCEL_BVH, dict(force_hbm_scene=1))):
+        with pkg.Scene(camd, objs, mats, accel=accel, collect_stats=True, tuning=tun) as s:
+            rgb, rgba = s.render_rows(0, 2, 3)
+            st = s.stats()
+        _assert_frames_equal(rgb, want)
+        assert np.array_equal(rgba, want8)
+        assert st["segments"] == ctr["segments"], st
+    # the same box with a limit of 300: most paths end black at the limit (core.cc:238-240), a few leak out
+    kwe = dict(kwd, max_depth=300, samples_per_pixel=16, image_width=8)
+    came, ocame = pkg.camera_setup(pkg.camera_params(**kwe)), ob.camera_setup(ob.camera_params(**kwe))
+    want, want8 = ob.render_rect_counter(ocame, objs, mats, 4, 0, 0, 8, 8, nthreads=8)
+    with pkg.Scene(came, objs, mats, accel=pkg.ACCEL_BVH) as s:
+        rgb, rgba = s.render_rows(0, 8, 4)
+    _assert_frames_equal(rgb, want)
+    assert np.array_equal(rgba, want8)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # boundary behaviour of the C-ABI
 # ---------------------------------------------------------------------------------------------------------------
@@ -332,7 +424,7 @@ def test_ragged_image_sizes_chunks_and_block_strides(pkg, ob, gpu):
         cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
         W, H = cam.img_width, cam.img_height
         want, want8 = ob.render_rect_counter(ocam, objs, mats, case, 0, 0, W, H)
-        with pkg.Scene(cam, objs, mats, tuning=dict(chunk_samples=chunk, defer_mode=1 if case & 1 else -1)) as s:
+        with pkg.Scene(cam, objs, mats, tuning=dict(chunk_samples=chunk)) as s:
             rgb, rgba = s.render_rows(0, H, case)
             _assert_frames_equal(rgb, want)
             assert np.array_equal(rgba, want8), (w, H, spp, chunk)
@@ -399,76 +491,6 @@ def test_device_pointer_entry_and_sharded_blocks(pkg, ob, rtow, gpu):
             assert np.array_equal(frame8, want8)
 
 
-@pytest.mark.parametrize("tuning", [dict(kernel=2), dict(kernel=2, wf_block_lanes=512, wf_slots=320, wf_refill=8),
-                                    dict(kernel=2, wf_refill=56, blocks_per_cu=1), dict(kernel=2, force_hbm_scene=1)])
-def test_queue_scheduled_kernel_matches_oracle(pkg, ob, rtow, gpu, tuning):
-    """rtmi_tuning::kernel = 2 (rtmi_wavefront.hip: path slots and rings in LDS, waves take homogeneous batches): same
-    draw streams, same arithmetic -- the oracle's frame bit for bit, the oracle's work counters, for LDS- and
-    HBM-resident scenes, deep bounces, depth limits 0 and 1, ragged images, sharded row blocks and banded calls."""
-    torch = gpu
-    kw = dict(image_width=144, samples_per_pixel=12, max_depth=50)
-    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
-    W, H = cam.img_width, cam.img_height
-    want, want8 = ob.render_rect_counter(ocam, *rtow, 71, 0, 0, W, H, nthreads=8)
-    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=tuning) as s:
-        rgb, rgba = s.render_rows(0, H, 71)
-        st = s.stats()
-        part, _ = s.render_rows(5, 23, 71)
-        # sharded row blocks through the device-pointer entry
-        dev = torch.device("cuda", 0)
-        plan = pkg.RowShardPlan(H, 8, 3)
-        parts = []
-        for r in range(3):
-            y_first, n_blocks, rows = plan.shard(r)
-            buf = torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev)
-            s.render_row_blocks_device(y_first, 8, 3, n_blocks, 71, buf.data_ptr(), 0, torch.cuda.current_stream(dev).cuda_stream)
-            parts.append(buf)
-        torch.cuda.synchronize()
-        s.last_kernel_ms()  # also reads the watchdog word
-        frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev)).cpu().numpy()
-    _assert_frames_equal(rgb, want)
-    assert np.array_equal(rgba, want8)
-    _assert_frames_equal(part, want[5:23])
-    _assert_frames_equal(frame, want)
-    assert st["samples"] == H * W * 12
-    # deep bounces (config 5 shape) and a banded call
-    g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
-    ccam = pkg.camera_setup(pkg.camera_params(**json.loads(str(g["camera"]))))
-    with pkg.Scene(ccam, g["objects"], g["materials"], accel=pkg.ACCEL_BVH, tuning=dict(tuning, sample_buf_mb=1)) as s:
-        crgb, crgba = s.render_rows(0, ccam.img_height, int(g["seed"]))
-    _assert_frames_equal(crgb, g["rgb"])
-    assert np.array_equal(crgba, g["rgba"])
-    # depth limits 0 and 1, ragged sizes
-    objs, mats = three_spheres()
-    for (w, aspect, spp, depth) in ((33, 1.0, 5, 0), (65, 3.0, 9, 1), (100, 16.0 / 9.0, 17, 7)):
-        k3 = dict(three_spheres_camera(), image_width=w, aspect_ratio=aspect, samples_per_pixel=spp, max_depth=depth)
-        c3, o3 = pkg.camera_setup(pkg.camera_params(**k3)), ob.camera_setup(ob.camera_params(**k3))
-        w3, w38 = ob.render_rect_counter(o3, objs, mats, 4, 0, 0, c3.img_width, c3.img_height)
-        with pkg.Scene(c3, objs, mats, accel=pkg.ACCEL_BVH, tuning=tuning) as s:
-            r3, r38 = s.render_rows(0, c3.img_height, 4)
-        _assert_frames_equal(r3, w3)
-        assert np.array_equal(r38, w38)
-
-
-def test_queue_scheduled_kernel_statistics(pkg, ob, rtow, gpu):
-    """Work counters of the queue-scheduled kernel equal the oracle's instrumented walk of the same tree."""
-    kw = dict(image_width=96, samples_per_pixel=8, max_depth=50)
-    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
-    bvh = pkg.bvh_build(rtow[0])
-    obvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
-    _, _, ctr = ob.render_rect_counter(ocam, *rtow, 3, 0, 0, ocam.img_width, ocam.img_height, nthreads=8, counters=True, bvh=obvh)
-    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=dict(kernel=2)) as s:
-        s.render_rows(0, cam.img_height, 3)
-        st = s.stats()
-    assert st["samples"] == ctr["samples"] and st["segments"] == ctr["segments"]
-    # v_rcp_f32 in the (conservative) slab test against the oracle's true division: visit counts differ in the last digits
-    for k in ("sphere_tests", "node_tests"):
-        assert abs(st[k] - ctr[k]) <= 1e-3 * ctr[k], (k, st[k], ctr[k])
-    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=dict(kernel=1)) as s:
-        s.render_rows(0, cam.img_height, 3)
-        assert s.stats() == st  # the two kernels walk the same tree with the same arithmetic
-
-
 def test_multi_device_frame_entry_degenerate_one_device(pkg, ob, rtow, gpu):
     """rtmi_frame_* with n = 1 (what one box offers): shard plan of one rank, no communicator, de-interleave kernel run
     on the identity map -- the frame must be bit-equal to rtmi_render_rows and to the oracle; also with a block size that
@@ -506,15 +528,94 @@ def test_multi_device_frame_entry_degenerate_one_device(pkg, ob, rtow, gpu):
     assert torch.cuda.current_device() == 0  # every entry point restores the caller's device
 
 
+def test_rccl_runs_with_a_one_rank_communicator(pkg, rtow, gpu):
+    """RTMI_FRAME_FORCE_RCCL makes the n = 1 frame do what n > 1 does -- librccl opened at run time,
+    ncclCommInitAll, ONE ncclGather per rank inside a group on the render stream (rank 0 gathers its packed float-RGB +
+    RGBA8 slice from itself), the de-interleave kernel behind it -- so that the multi-GPU code path has executed before
+    the driver's 8-GPU run.  Frame bit-equal to rtmi_render_rows, also twice in a row and with a ragged block size."""
+    torch = gpu
+    kw = dict(image_width=150, samples_per_pixel=6, max_depth=50)
+    cam = pkg.camera_setup(pkg.camera_params(**kw))
+    H = cam.img_height
+    with pkg.Scene(cam, *rtow) as s:
+        ref, ref8 = s.render_rows(0, H, 21)
+        ref_b, _ = s.render_rows(0, H, 22)
+    for block_rows in (8, 5):
+        with pkg.Frame(cam, *rtow, devices=(0,), block_rows=block_rows, force_rccl=True) as f:
+            assert f.rccl_ranks == 1
+            rgb, rgba = f.render(21)
+            t = f.timing()
+            assert t["gather_ms"] > 0.0 and t["kernel_ms"][0] > 0.0
+            rgb_b, _ = f.render(22)
+            rgb_c, rgba_c = f.render(21)
+        assert rgb.tobytes() == ref.tobytes() and np.array_equal(rgba, ref8)
+        assert rgb_b.tobytes() == ref_b.tobytes()
+        assert rgb_c.tobytes() == ref.tobytes() and np.array_equal(rgba_c, ref8)
+    assert torch.cuda.current_device() == 0
+
+
+def test_bench_force_dist_runs_the_rccl_process_group_with_one_rank(gpu):
+    """`bench.py --gpus 1 --force-dist`: the launcher starts one rank under torch.distributed.run before anything touches
+    the GPU, the rank initialises the "nccl" (RCCL) process group and sends its frame through the gather collective and
+    the timing all-reduce with world size 1; `--single-process --force-dist` does the same inside librtmi.so."""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--config", "2", "--width", "160",
+            "--spp", "8", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-linear-scan"]
+    for extra in ([], ["--single-process"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        doc = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert doc["rccl_ranks"] == 1 and doc["n_gpus"] == 1 and doc["value"] > 0, doc
+        if not extra:
+            assert doc["parity_check"]["max_abs_diff_vs_oracle"] == 0.0 and "nccl" in doc["config"]["launcher"]
+
+
+def test_multi_device_frame_over_rccl(pkg, rtow, gpu):
+    """the real n > 1 path -- one rank per device, ncclCommInitAll(n), the grouped gather over xGMI -- on boxes
+    that have more than one GPU (skipped on the one-GPU box): frame bit-equal to rtmi_render_rows, rccl_ranks == n."""
+    torch = gpu
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("one visible GPU: RCCL with n > 1 needs one device per rank")
+    kw = dict(image_width=200, samples_per_pixel=8, max_depth=50)
+    cam = pkg.camera_setup(pkg.camera_params(**kw))
+    with pkg.Scene(cam, *rtow, device=0) as s:
+        ref, ref8 = s.render_rows(0, cam.img_height, 5)
+    for n in sorted({2, min(n_dev, 6)}):  # (the box allows six processes / contexts on its cards)
+        with pkg.Frame(cam, *rtow, devices=tuple(range(n)), block_rows=8) as f:
+            assert f.rccl_ranks == n
+            rgb, rgba = f.render(5)
+            rgb2, _ = f.render(5)
+        assert rgb.tobytes() == ref.tobytes() and np.array_equal(rgba, ref8) and rgb2.tobytes() == ref.tobytes(), n
+
+
+def test_scene_just_below_the_lds_limit_keeps_two_workgroups_per_cu(pkg, gpu):
+    """the LDS-residency test and the carve-up use one expression: a scene whose staged size lands within a
+    kilobyte of 80 KiB either stays in HBM or still runs two workgroups per CU -- never one."""
+    cam = pkg.camera_setup(pkg.camera_params(image_width=32, samples_per_pixel=1, max_depth=4))
+    seen_lds = seen_hbm = False
+    for n in range(700, 1100, 4):
+        objs, mats = random_spheres(n, seed=3)
+        with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as s:
+            li = s.launch_info()
+        if li["scene_in_lds"]:
+            seen_lds = True
+            assert li["lds_bytes"] <= 80 * 1024 and li["blocks_per_cu"] == 2, (n, li)
+        else:
+            seen_hbm = True
+    assert seen_lds and seen_hbm  # the sweep crossed the limit
+
+
 def test_images_wider_than_16_bit_coordinates(pkg, ob, gpu):
-    """A deferred-path record holds the pixel's index within the call (32 bits; round 1 packed x | y << 16 and had to keep
-    the paths of launches wider than 65535 pixels) -- 70000 x 8 with the queue forced on."""
+    """Pixel indices are 32-bit everywhere (round 1 packed x | y << 16 into its deferred-path records): 70000 x 8."""
     objs, mats = three_spheres()
     kw = dict(three_spheres_camera(), image_width=70000, aspect_ratio=70000.0 / 8.0, samples_per_pixel=8, max_depth=24)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
     assert (cam.img_width, cam.img_height) == (70000, 8)
     want, want8 = ob.render_rect_counter(ocam, objs, mats, 3, 0, 0, 70000, 8, nthreads=8)
-    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=dict(defer_mode=1, chunk_samples=2)) as s:
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=dict(chunk_samples=2)) as s:
         rgb, rgba = s.render_rows(0, 8, 3)
     _assert_frames_equal(rgb, want)
     assert np.array_equal(rgba, want8)
@@ -755,7 +856,7 @@ def test_bvh_walk_equals_linear_scan_on_generated_worlds(pkg, gpu):
                       focus_distance=10.0, lookfrom=(far, 0.3 * far + 1.0, 0.5 * far), lookat=(0.0, 0.0, 0.0),
                       world_up=(0.0, 1.0, 0.0))
         cam = pkg.camera_setup(pkg.camera_params(**kw))
-        d = _bvh_equals_scan(pkg, cam, objs, mats, 77 + i, tunings=(dict(kernel=1), dict(kernel=2)))
+        d = _bvh_equals_scan(pkg, cam, objs, mats, 77 + i, tunings=(dict(kernel=1),))
         if d:
             bad[i] = d
     assert not bad, bad
@@ -790,7 +891,7 @@ def test_bvh_walk_equals_linear_scan_on_grazing_rays(pkg, gpu):
                       focus_distance=dist, lookfrom=tuple(float(v) for v in O), lookat=tuple(float(v) for v in limb),
                       world_up=(0.0, 1.0, 0.0))
             cam = pkg.camera_setup(pkg.camera_params(**kw))
-            d = _bvh_equals_scan(pkg, cam, objs, mats, 5, tunings=(dict(kernel=1), dict(kernel=2)))
+            d = _bvh_equals_scan(pkg, cam, objs, mats, 5, tunings=(dict(kernel=1),))
             assert d == 0, (target, R, L, d)
             checked += 1
     assert checked >= 15

@@ -84,7 +84,7 @@ def test_scene_create_argument_errors(pkg):
     info = pkg.LaunchInfo()
     info.struct_size = C.sizeof(pkg.LaunchInfo)
     assert pkg.lib().rtmi_scene_get_launch_info(None, C.byref(info)) == pkg.RTMI_ERR_BAD_ARG
-    assert C.sizeof(pkg.LaunchInfo) == 32
+    assert C.sizeof(pkg.LaunchInfo) == 36
     pkg.lib().rtmi_scene_destroy(None)  # no-op
 
 
@@ -135,7 +135,7 @@ def test_tuning_struct_layout_and_unknown_knobs(pkg):
         pkg.make_tuning(no_such_knob=1)
     header = open(os.path.join(ROOT, "include", "rtmi.h")).read()
     body = header[header.index("typedef struct rtmi_tuning {"):header.index("} rtmi_tuning;")]
-    fields = re.findall(r"^\s+u?int32_t\s+([a-z_]+)(?:\[\d+\])?;", body, flags=re.M)
+    fields = re.findall(r"^\s+u?int32_t\s+([a-z_0-9]+)(?:\[\d+\])?;", body, flags=re.M)
     assert fields == [n for n, _ in pkg.Tuning._fields_]
     # the library reads no environment variables
     for src in ("rtmi_device.hip", "rtmi_host.cpp", "rtmi_frame.hip"):
