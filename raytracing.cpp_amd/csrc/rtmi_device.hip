@@ -235,6 +235,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
     t.cur = kStackEnd; // "not walking" (see the traversal loop)
     uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0;
     PF_DECL
+    PB_DECL
 
     // attenuation chain: material handles of the non-dielectric bounces of the live path, run-length encoded (a path
     // trapped inside the ground sphere bounces 50 times on the same material: one run).  The open run lives in two
@@ -310,6 +311,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
         if (ACCEL == RTMI_ACCEL_BVH) {
             t.cur = P.root_ref;
             t.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+            PF_MARK(17);
             float pad = P.pad_floor;
             for (uint32_t c = 0; c < P.n_pad_classes; ++c) {
                 const float* k = P.pad_classes[c];
@@ -323,6 +325,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             }
             t.oinv = mk(-(o.x * t.inv.x), -(o.y * t.inv.y), -(o.z * t.inv.z));
             t.pinv = mk(pad * __builtin_fabsf(t.inv.x), pad * __builtin_fabsf(t.inv.y), pad * __builtin_fabsf(t.inv.z));
+            PF_MARK(18);
             // Leaves that hang directly off the top of the tree -- the ground sphere, whose box is the whole scene; the
             // walls of a box made of huge spheres -- are tested here, by all the lanes that start a segment, and the
             // walk begins below them with the far limit already set: one node trip and one leaf trip less per leaf
@@ -340,6 +343,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                     test_leaf(ref);
                 }
             }
+            PF_MARK(19);
         } else {
             t.cur = 0; // next sphere of the linear scan
         }
@@ -347,10 +351,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
     };
 
     for (;;) {
-        PF_MARK(pf9);
-        PF_COUNT(pf10);
+        PF_MARK(16);
         // ---- FETCH: one wave-aggregated atomic hands out consecutive indices of the 8x8-tiled pixel space -----
         ISA_MARK("fetch");
+        PB(21, true);
+        PB(0, phase == PH_FETCH);
         while (phase == PH_FETCH) {
             const uint64_t need = ballot(true);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -393,11 +398,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             }
         }
         if (ballot(phase != PH_DONE) == 0ull) break;
-        PF_MARK(pf0);
-        PF_LANES(pl5, ballot(phase == PH_GEN));
+        PF_MARK(0);
 
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
         ISA_MARK("gen");
+        PB(1, phase == PH_GEN);
         if (phase == PH_GEN) {
             const uint32_t gy = fdiv(rng.pixel, P.div_w), px = rng.pixel - gy * W; // (rng.pixel = gy * W + px came with the work item)
             rng.k = 0;
@@ -414,12 +419,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                 // random_vector_on_unit_disk, random.number.gen.hpp:35-42
                 float dx = draw_pm1(gb.w2), dy = draw_pm1(gb.w3);
                 rng.k = 4;
+                ISA_MARK("gen-disk-retry");
+                PF_MARK(1);
                 while (!(vdot(mk(dx, dy, 0.0f), mk(dx, dy, 0.0f)) < 1.0f)) { // two attempts per further block
+                    PB(2, true);
                     if ((rng.k & 3u) == 0u) gb = rng_block(rng, rng.k >> 2, P.seed);
                     dx = draw_pm1((rng.k & 3u) ? gb.w2 : gb.w0);
                     dy = draw_pm1((rng.k & 3u) ? gb.w3 : gb.w1);
                     rng.k += 2u;
                 }
+                PF_MARK(20);
+                ISA_MARK("gen-tail");
                 origin = vadd(vadd(ld3(P.cam.cam_center), vscale(ld3(P.cam.defocus_disk_u), dx)),
                               vscale(ld3(P.cam.defocus_disk_v), dy));
             }
@@ -437,10 +447,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             }
         }
         // every new segment of this round -- primary rays, scattered rays, resumed paths -- is set up here, once
-        PF_MARK(pf1);
+        PF_MARK(1);
         ISA_MARK("begin");
+        PB(3, phase == PH_BEGIN);
         if (phase == PH_BEGIN) {
-            PF_LANES(pl6, ballot(true));
             begin_segment(t.o, t.d);
             phase = (ACCEL == RTMI_ACCEL_BVH && P.root_ref == kNoWalk) ? PH_SHADE : PH_TRAV;
         }
@@ -449,7 +459,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
         // (A/B on MI355X: +1.3 %; the other way round -0.4 %)
         ISA_MARK("walk");
         __builtin_amdgcn_s_setprio(1);
-        PF_MARK(pf6);
+        PF_MARK(2);
         // ---- TRAVERSE ---------------------------------------------------------------------------------------------
         if (ACCEL == RTMI_ACCEL_BVH) {
             // Two kinds of step: an internal node (two slab tests) or a leaf (its spheres).  Each iteration the wave
@@ -463,7 +473,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             // ten more s_add per trip cost the frame 4.3 %, ten more v_mov 2.8 %, measured).
             const int trav_floor = max(0, (int)__popcll(ballot(phase == PH_TRAV || phase == PH_SHADE)) - (int)P.wait_thresh);
             for (;;) {
-#if RTMI_ASM_WALK && !defined(RTMI_PROF)
+#if RTMI_ASM_WALK && !(defined(RTMI_PROF) && RTMI_PROF == 1)
                 if (!BIG && !STATS) {
                     int n_leaf, n_node;
                     walk_nodes_lds(t, lds0, sp_stride, trav_floor, n_leaf, n_node); // nodes start the dynamic LDS segment
@@ -479,9 +489,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                 const bool at_leaf = (int32_t)t.cur < -1, at_node = (int32_t)t.cur >= 0; // (inline constants)
                 const uint64_t m_leaf = ballot(at_leaf);
                 const uint64_t m_node = ballot(at_node);
-                PF_COUNT(pf11);
-#ifdef RTMI_PROF
-                if (__popcll(m_leaf) > __popcll(m_node)) { PF_COUNT(pl0); PF_LANES(pl1, m_leaf); PF_LANES(pf7, m_node); } else { PF_LANES(pl2, m_node); PF_LANES(pf4, m_leaf); }
+#if defined(RTMI_PROF) && RTMI_PROF == 1
+                // pfl: 0 leaf trips, 1 lanes stepping in them, 2 lanes parked at a node meanwhile; 3 node trips, 4 lanes stepping, 5 parked at a leaf
+                if (__popcll(m_leaf) > __popcll(m_node)) { PF_COUNT(0); PF_LANES(1, m_leaf); PF_LANES(2, m_node); } else if (__popcll(m_leaf) + __popcll(m_node) > trav_floor) { PF_COUNT(3); PF_LANES(4, m_node); PF_LANES(5, m_leaf); }
 #endif
                 int n_leaf = (int)__popcll(m_leaf), n_node = (int)__popcll(m_node);
                 // keep the counts 32-bit scalars: left alone the compiler compares the 64-bit popcounts, for which
@@ -491,10 +501,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                 // (one merged pop behind both branches: writing it out in each of them was measured 3 % slower)
                 bool pop = false;
                 if (n_leaf > n_node) {
+                    PF_MARK(3);
                     if (at_leaf) {
                         test_leaf(t.cur);
                         pop = true;
                     }
+                    PF_MARK(21);
                 } else if (at_node) {
                     NodeFields nd;
                     if (BIG) { // 48-byte records read through L1 / L2 / Infinity Cache (config 4)
@@ -578,22 +590,22 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             }
         }
 
-        PF_MARK(pf2);
-        PF_LANES(pl3, ballot(phase == PH_SHADE));
-        PF_LANES(pl4, ballot(phase == PH_SHADE && t.best == ~0u));
-        PF_LANES(pl7, ballot(phase == PH_DONE));
+        PF_MARK(3);
+        PF_LANES(6, ballot(phase == PH_DONE));
         // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
         // unit vectors for every Lambertian / Metallic hit of this round, generated by the whole wave together
         ISA_MARK("request");
         __builtin_amdgcn_s_setprio(0);
         uint32_t rq = RQ_NONE; // Lambertian / Metallic hit: a unit vector; Dielectric hit: one draw
         if (phase == PH_SHADE && t.best < kBlackSample) rq = lds_aux[t.best].w != 2u ? RQ_UNIT : RQ_WORD;
-        PF_MARK(pf8);
+        PF_MARK(4);
         ISA_MARK("draws");
         rng.sample = s; // (defined where it is used: not a register across the walk)
-        const V3 unit_vec = coop_draws(rq, rng, P.seed, rank_tbl);
+        const V3 unit_vec = coop_draws(rq, rng, P.seed, rank_tbl PB_PASS);
         ISA_MARK("shade");
-        PF_MARK(pf5);
+        PF_MARK(7);
+        PB(8, phase == PH_SHADE);
+        PB(22, rq == RQ_WORD || (phase == PH_SHADE && t.best == ~0u)); // the shared normalize(ray.direction)
         if (phase == PH_SHADE) {
             bool ended = false;
             V3 color = mk(0.0f, 0.0f, 0.0f);
@@ -605,6 +617,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             if (t.best == kBlackSample) {
                 ended = true; // maxdepth == 0: black sample
             } else if (t.best != ~0u) {
+                ISA_MARK("shade-hit-record");
+                PF_MARK(8);
+                PB(9, true);
                 // IntersectionRecord for the winning sphere, object.defs.cc:62-65 and :11-18
                 const uint4 sraw = lds_spheres[t.best];
                 const uint4 araw = lds_aux[t.best];
@@ -618,9 +633,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                 const uint32_t mh = araw.y;
                 const uint4 m0 = lds_mats[mh]; // {albedo, fuzz} or {refraction index, ...}
                 ISA_MARK("shade-material");
+                PF_MARK(9);
                 const uint32_t kind = araw.w;
                 V3 sd = mk(0.0f, 0.0f, 0.0f);
                 bool scattered = true;
+                PB(10, kind == 0u);
+                PB(11, kind == 1u);
+                PB(12, kind == 2u);
                 if (kind != 2u) {
                     // Lambertian (material.defs.cc:31-42) and Metallic (:44-55) share ONE rejection loop for their
                     // random_unit_vector(): the wave pays the longest run of rejections once, not once per material.
@@ -635,7 +654,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                         sd = vadd(rn, vscale(u, __uint_as_float(m0.w)));
                         scattered = vdot(sd, N) > 0.0f;
                     }
+                    PF_MARK(10);
                 } else { // Material_Dielectric::scatter, material.defs.cc:57-87
+                    ISA_MARK("shade-dielectric");
                     // eta = front ? 1/ri : ri and r1 = ((1 - eta) / (1 + eta))^2 (material.defs.cc:58, 80-82) depend on the
                     // material and the face only: both pairs are computed once on the host with the same fp32 operations
                     const float eta = front ? __uint_as_float(m0.y) : __uint_as_float(m0.x);
@@ -643,6 +664,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                     const float cos_theta = fminf(vdot(vneg(unit_dir), N), 1.0f);
                     const float sin_theta = sqrt_shared(1.0f - cos_theta * cos_theta);
                     bool reflect_it = (eta * sin_theta) > 1.0f;
+                    PB(13, !reflect_it);
                     if (!reflect_it) { // short-circuit ||: the draw happens only when refraction is possible
                         // powf(x, 5): x^5 through double is the correctly rounded value except for ties
                         const double xd = (double)(1.0f - cos_theta);
@@ -654,6 +676,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                         reflect_it = (double)schlick > u;
                     }
                     sd = reflect_it ? vreflect(unit_dir, N) : vrefract(unit_dir, N, eta);
+                    PF_MARK(11);
                 }
                 ISA_MARK("shade-continue");
                 if (!scattered) {
@@ -669,11 +692,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                         phase = PH_BEGIN; // set up before the next traversal, together with the new primary rays
                     }
                 }
+                PF_MARK(12);
             } else {
                 ISA_MARK("shade-miss");
+                PF_MARK(8);
+                PB(14, true);
+                PB(15, natt != 0u || run_n != 0u);
                 // miss: sky gradient (core.cc:254-256), then the attenuations innermost-first (core.cc:247-248)
                 const float tt = 0.5f * (unit_dir.y + 1.0f);
                 color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
+                ISA_MARK("shade-replay");
+                PF_MARK(13);
                 color = att_apply(color, run_h, run_n);
                 if (!BIG) {
                     const uint32_t full = natt >> 2; // whole windows that went to HBM; the rest is still in LDS
@@ -697,8 +726,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                     }
                 }
                 ended = true;
+                PF_MARK(14);
             }
             ISA_MARK("shade-ended");
+            PB(16, ended);
+            PB(17, ended && t.best != ~0u);
             if (ended) {
                 // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
                 if (!WHOLE) {
@@ -734,21 +766,24 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                 } else {
                     phase = PH_GEN;
                 }
+                PF_MARK(15);
             }
         }
-        PF_MARK(pf3);
         ISA_MARK("loop-end");
     }
 
-#ifdef RTMI_PROF
-    PF_MARK(pf9);
+#if defined(RTMI_PROF) && RTMI_PROF == 1
+    PF_MARK(16);
     if (lane == 0) {
-        unsigned long long* const pst = P.stats;
-        atomicAdd(&pst[8], pf0); atomicAdd(&pst[9], pf1); atomicAdd(&pst[10], pf2); atomicAdd(&pst[11], pf3);
-        atomicAdd(&pst[12], pf4); atomicAdd(&pst[13], pf5); atomicAdd(&pst[14], pf6); atomicAdd(&pst[15], pf7);
-        atomicAdd(&pst[16], pf8); atomicAdd(&pst[17], pf9); atomicAdd(&pst[18], pf10); atomicAdd(&pst[19], pf11);
-        atomicAdd(&pst[20], pl0); atomicAdd(&pst[21], pl1); atomicAdd(&pst[22], pl2); atomicAdd(&pst[23], pl3);
-        atomicAdd(&pst[24], pl4); atomicAdd(&pst[25], pl5); atomicAdd(&pst[26], pl6); atomicAdd(&pst[27], pl7);
+        for (int q = 0; q < PF_SLOTS; ++q) atomicAdd(&P.stats[8 + q], (unsigned long long)pft[q]);
+        for (int q = 0; q < 12; ++q) atomicAdd(&P.stats[32 + q], (unsigned long long)pfl[q]);
+    }
+#elif defined(RTMI_PROF)
+    if (lane == 0) {
+        for (int q = 0; q < PB_SLOTS; ++q) {
+            atomicAdd(&P.stats[64 + 2 * q], (unsigned long long)pb_n[q]);
+            atomicAdd(&P.stats[65 + 2 * q], (unsigned long long)pb_l[q]);
+        }
     }
 #endif
     if (STATS) {
@@ -1481,8 +1516,8 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
 #endif
 
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_counter), 16));
-    HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 64 * sizeof(unsigned long long)));
-    HIP_TRY_S(hipMemset(s->d_stats, 0, 64 * sizeof(unsigned long long)));
+    HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 128 * sizeof(unsigned long long)));
+    HIP_TRY_S(hipMemset(s->d_stats, 0, 128 * sizeof(unsigned long long)));
     const size_t att_lanes = std::max<size_t>((size_t)s->grid * s->block, (size_t)s->wf_grid * s->wf_slots);
     const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * att_lanes * 2u * sizeof(uint32_t));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_att), att_bytes));
@@ -1669,9 +1704,9 @@ extern "C" int rtmi_scene_last_kernel_ms(rtmi_scene* s, float* ms_out) {
 }
 
 #ifdef RTMI_PROF
-extern "C" int rtmi_prof_read(rtmi_scene* s, unsigned long long* out32) {
+extern "C" int rtmi_prof_read(rtmi_scene* s, unsigned long long* out128) {
     hipSetDevice(s->device);
     hipDeviceSynchronize();
-    return hipMemcpy(out32, s->d_stats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+    return hipMemcpy(out128, s->d_stats, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 #endif

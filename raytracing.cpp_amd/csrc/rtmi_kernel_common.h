@@ -118,16 +118,38 @@ DEV NodeFields unpack_node64(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
 
 // In-kernel stamps (diagnostic build only, -DRTMI_PROF): s_memtime deltas per phase of the v1 kernel, summed per wave
 // into stats[8 + i].  Never compiled into the shipped library.
-#ifdef RTMI_PROF
-#define PF_DECL unsigned long long pf_t = __builtin_readcyclecounter(), pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0, pf7 = 0, pf8 = 0, pf9 = 0, pf10 = 0, pf11 = 0, pl0 = 0, pl1 = 0, pl2 = 0, pl3 = 0, pl4 = 0, pl5 = 0, pl6 = 0, pl7 = 0;
-#define PF_MARK(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - pf_t; pf_t = n_; } while (0)
-#define PF_COUNT(acc) do { acc += 1; } while (0)
-#define PF_LANES(acc, mask) do { acc += (unsigned long long)__popcll(mask); } while (0)
+// In-kernel stamps and counters (diagnostic builds only, never the shipped library; tools/branch_census.py):
+//   -DRTMI_PROF=1  pft[i]: cycles (s_memtime deltas) of section i of a round; pfl[i]: trips and lanes of the walk
+//   -DRTMI_PROF=2  branch census: how often a piece of code runs with at least one lane (pb_n) and with how many (pb_l)
+// All of them are wave-uniform 32-bit scalars (two builds, because together they do not fit the scalar registers),
+// added into P.stats[8 ..], [32 ..], [64 + 2 i] at the end of the kernel.
+#define PF_SLOTS 24
+#define PB_SLOTS 24
+#if defined(RTMI_PROF) && RTMI_PROF == 1
+#define PF_DECL uint32_t pf_t = (uint32_t)__builtin_readcyclecounter(), pft[PF_SLOTS] = {}, pfl[12] = {};
+#define PF_MARK(i) do { const uint32_t n_ = (uint32_t)__builtin_readcyclecounter(); pft[i] += n_ - pf_t; pf_t = n_; } while (0)
+#define PF_COUNT(i) do { pfl[i] += 1u; } while (0)
+#define PF_LANES(i, mask) do { pfl[i] += (uint32_t)__popcll(mask); } while (0)
+#define PB_ARGS , uint32_t* pft, uint32_t& pf_t
+#define PB_PASS , pft, pf_t
 #else
 #define PF_DECL
-#define PF_MARK(acc) do { } while (0)
-#define PF_COUNT(acc) do { } while (0)
-#define PF_LANES(acc, mask) do { } while (0)
+#define PF_MARK(i) do { } while (0)
+#define PF_COUNT(i) do { } while (0)
+#define PF_LANES(i, mask) do { } while (0)
+#endif
+#if defined(RTMI_PROF) && RTMI_PROF == 2
+#define PB_DECL uint32_t pb_n[PB_SLOTS] = {}, pb_l[PB_SLOTS] = {};
+#define PB(i, cond) do { const uint64_t m_ = __builtin_amdgcn_ballot_w64(cond); pb_n[i] += m_ != 0ull ? 1u : 0u; pb_l[i] += (uint32_t)__popcll(m_); } while (0)
+#define PB_ARGS , uint32_t* pb_n, uint32_t* pb_l
+#define PB_PASS , pb_n, pb_l
+#else
+#define PB_DECL
+#define PB(i, cond) do { } while (0)
+#endif
+#ifndef PB_ARGS
+#define PB_ARGS
+#define PB_PASS
 #endif
 
 // Static code map (diagnostic build only, -DRTMI_MARKS): comment lines in the ISA at the phase boundaries, so that
@@ -318,13 +340,16 @@ constexpr int kSelfAttempts = 2; // measured on config 3: 0 -> 159.4 ms, 1 -> 15
 
 // (an LDS-qualified pointer: through a generic one these accesses become flat_* instructions with full waits)
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
-DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
+DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl PB_ARGS) {
     V3 out = mk(0.0f, 0.0f, 0.0f);
     if (code == RQ_UNIT) rng.k = (rng.k + 3u) & ~3u; // attempts are block aligned
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     bool pending = code != RQ_NONE;
 #pragma unroll 1
+    PB(7, code == RQ_WORD);
+    ISA_MARK("coop-owner");
     for (int self = 0; self < kSelfAttempts; ++self) {
+        PB(4 + (self ? 1 : 0), pending);
         if (pending) {
             Blk tmp;
             rng4x32(rng.k >> 2, rng.sample, rng.pixel, seed, tmp);
@@ -345,7 +370,10 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
     }
     // from here on every pending lane is an RQ_UNIT one
     uint64_t todo = ballot(pending);
+    ISA_MARK("coop-shared");
+    PF_MARK(5);
     while (todo != 0ull) {
+        PB(6, pending);
         const uint32_t n = (uint32_t)__popcll(todo);
         // attempts per pending lane in this pass: min(64 / n, 8) as a compare chain (an integer division by a run-time
         // value is a dozen instructions) together with the bits c * n, c < per, of the acceptance vote
@@ -399,6 +427,8 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl) {
     // p / sqrt(dot(p, p)) once, on the owner's lane: the IEEE square root and divisions are not paid per attempt
     // (components are multiples of 2^-31 in (-1, 1), +0 included, and 2^-31 <= sqrt <= 1: always in range)
     // (and 2^-62 <= dot <= 1 for the square root)
+    ISA_MARK("coop-normalize");
+    PF_MARK(6);
     if (code == RQ_UNIT) out = vdivs_shared(out, sqrt_core(vdot(out, out)), true);
     return out;
 }

@@ -23,10 +23,10 @@ else:
 with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
     sc.render_rows(0, cam.img_height, 7)
     ms = sc.last_kernel_ms()
-    out = (C.c_ulonglong * 64)()
+    out = (C.c_ulonglong * 128)()
     pkg.lib().rtmi_prof_read(sc._h, out)
 names = ["fetch", "gen", "traverse", "shade", "-", "coop-unit", "begin-seg", "-", "pre-coop", "loop-glue", "#rounds", "#trav-iters"]
-for label, base in (("primary", 0), ("drain", 32)):
+for label, base in (("trace", 0),):
     v = [int(x) for x in out[base + 8:base + 20]]
     idle_leaf, idle_node = v[4], v[7]  # lanes waiting at a leaf during node trips / at a node during leaf trips
     v[4] = v[7] = 0
