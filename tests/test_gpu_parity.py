@@ -596,7 +596,7 @@ def test_scene_just_below_the_lds_limit_keeps_two_workgroups_per_cu(pkg, gpu):
     kilobyte of 80 KiB either stays in HBM or still runs two workgroups per CU -- never one."""
     cam = pkg.camera_setup(pkg.camera_params(image_width=32, samples_per_pixel=1, max_depth=4))
     seen_lds = seen_hbm = False
-    for n in range(700, 1100, 4):
+    for n in range(480, 800, 2):
         objs, mats = random_spheres(n, seed=3)
         with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as s:
             li = s.launch_info()
