@@ -110,7 +110,9 @@ typedef struct rtmi_tuning {
     uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 52) */
     uint32_t reserved0;         /* (was drain_wait_thresh: the deferred-path queue of rounds 1-2 is gone) must be 0 */
     int32_t chunk_samples;      /* samples per work item: 0 = auto, -1 = whole pixels (no sample records), n > 0 = n */
-    int32_t reserved1;          /* (was defer_mode) ignored */
+    int32_t chain_mode;         /* attenuation chains: 0 = auto (packed strings of material handles in LDS, multiplied by the
+                                 * resolve pass, when they fit next to the scene; else run-length encoded runs with per-lane
+                                 * strips in HBM, multiplied at path end), 1 = always the run-length encoded form */
     uint32_t reserved2;         /* (was defer_cap) ignored */
     uint32_t sample_buf_mb;     /* cap on the sample-record buffer in MiB (default 24576); larger calls run in row bands */
     uint32_t force_hbm_scene;   /* nonzero: leave the scene in HBM even when it fits LDS (the config-4 path) */
@@ -213,6 +215,7 @@ typedef struct rtmi_launch_info {
     uint32_t whole_pixel_fallbacks; /* launches so far whose sample-record buffer (16 B per sample of the call, capped by
                              * rtmi_tuning::sample_buf_mb) could not be allocated: they ran with whole-pixel work items --
                              * the same image, but a longer tail at the end of the launch */
+    uint32_t packed_chains; /* 0: run-length encoded attenuation chains; else the words per sample of the packed form */
 } rtmi_launch_info;
 int rtmi_scene_get_launch_info(const rtmi_scene* scene, rtmi_launch_info* out);
 /* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), rmax^2}. */

@@ -82,7 +82,7 @@ class WorldDef(C.Structure):  # rtmi_world_def == reference src/ray.tracer.core.
 class Tuning(C.Structure):  # rtmi_tuning: scheduling knobs, 0 = default; none of them changes the image
     _fields_ = [("struct_size", C.c_uint32), ("block_lanes", C.c_uint32), ("blocks_per_cu", C.c_uint32),
                 ("wait_thresh", C.c_uint32), ("reserved0", C.c_uint32), ("chunk_samples", C.c_int32),
-                ("reserved1", C.c_int32), ("reserved2", C.c_uint32), ("sample_buf_mb", C.c_uint32),
+                ("chain_mode", C.c_int32), ("reserved2", C.c_uint32), ("sample_buf_mb", C.c_uint32),
                 ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("kernel", C.c_uint32),
                 ("wf_block_lanes", C.c_uint32), ("wf_slots", C.c_uint32), ("wf_refill", C.c_uint32),
                 ("reserved", C.c_uint32 * 1)]
@@ -95,7 +95,8 @@ class SceneOptions(C.Structure):
 
 class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("struct_size", "kernel", "block_lanes", "grid_blocks", "blocks_per_cu",
-                                          "lds_bytes", "scene_in_lds", "stack_depth", "whole_pixel_fallbacks")]
+                                          "lds_bytes", "scene_in_lds", "stack_depth", "whole_pixel_fallbacks",
+                                          "packed_chains")]
 
 
 class FrameTiming(C.Structure):
@@ -106,7 +107,7 @@ def make_tuning(**kw):
     """rtmi_tuning from keyword arguments (field names of include/rtmi.h); unknown names are an error."""
     t = Tuning()
     t.struct_size = C.sizeof(Tuning)
-    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved", "reserved0", "reserved1", "reserved2"}
+    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved", "reserved0", "reserved2"}
     for k, v in kw.items():
         if k not in names:
             raise KeyError(f"unknown tuning knob {k!r}")

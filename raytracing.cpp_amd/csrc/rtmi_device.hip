@@ -166,9 +166,12 @@ template <int ACCEL, bool STATS, bool BIG, int MODE>
 // 64 VGPRs, which they fit without spilling -- and run as two 896-lane workgroups per CU, 7 waves per SIMD: -3.4 %)
 __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 : RTMI_WPE))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     // MODE 0: work items are chunks of a pixel's samples, one 16-byte record per sample; 3: whole-pixel work items (no
-    // sample records: the lane adds its pixel's samples up itself).  (Modes 1 / 2, the deferred-path queue and its drain
-    // launch of rounds 1-2, were measured 8 % slower on the final round-2 kernel and are gone: DESIGN.md 5.1.)
-    constexpr bool WHOLE = MODE == 3;
+    // sample records: the lane adds its pixel's samples up itself); 4: as 0, with the attenuation chain as a packed string
+    // of material handles in LDS that leaves with the sample record and is multiplied by the resolve pass (scenes whose
+    // strings fit the LDS: few materials or a low bounce limit; the box of config 5).  (Modes 1 / 2, the deferred-path
+    // queue and its drain launch of rounds 1-2, were measured 8 % slower on the final round-2 kernel and are gone.)
+    constexpr bool WHOLE = MODE == 3, PACKED = MODE == 4;
+    static_assert(!(PACKED && BIG), "packed chains live next to an LDS-resident scene");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
     // traversal stack: entry 0 of every lane holds a sentinel that ends the walk when it is popped.  References are
@@ -263,7 +266,24 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             P.att_stack[((size_t)glane * maxdepth + q) * 2u + 1u] = n;
         }
     };
+    // MODE 4 keeps the chain as a string of handles instead: run_h = the word being filled, run_n = bits used in it |
+    // index of that word << 8, natt = handles so far.  A path of the config-5 box changes material at nearly every one
+    // of its 79 bounces: run-length encoding buys nothing there, the strips it spilled to were 27x the algorithmic HBM
+    // traffic of the launch (r02 profile) and the multiplication at the end of a path ran for one or two lanes of a wave
+    // at a time.  Here the string stays in LDS while the path lives, leaves in 16-byte stores next to the sample record
+    // when the path reaches the sky, and the resolve pass -- one lane per pixel, every lane busy -- does the multiplying.
     auto att_push = [&](uint32_t h) {
+        if (PACKED) {
+            run_h |= h << (run_n & 255u);
+            run_n += P.att_bits;
+            natt++;
+            if ((run_n & 255u) + P.att_bits > 32u) { // no room for another handle: the word goes to LDS
+                lds_att[(run_n >> 8) * blockDim.x + threadIdx.x] = run_h;
+                run_h = 0u;
+                run_n = (run_n & ~255u) + 256u;
+            }
+            return;
+        }
         if (run_n != 0u && h == run_h) {
             run_n++;
         } else {
@@ -436,6 +456,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             depth_left = P.cam.maxdepth;
             natt = 0;
             run_n = 0;
+            if (PACKED) run_h = 0;
             if (depth_left == 0) {
                 // compute_color(depth == 0) returns 0 at once (core.cc:238-240): the sample is black
                 t.best = kBlackSample; // marker read by SHADE: finish the sample without tracing
@@ -703,6 +724,19 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                 color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
                 ISA_MARK("shade-replay");
                 PF_MARK(13);
+                if (PACKED) {
+                    // the string leaves with the sample: whole 16-byte groups of words (the slot is a multiple of four
+                    // words; rows past the last written one are never read back)
+                    if (natt != 0u) {
+                        uint32_t nw = run_n >> 8;
+                        if ((run_n & 255u) != 0u) lds_att[nw++ * blockDim.x + threadIdx.x] = run_h;
+                        uint4* dst = reinterpret_cast<uint4*>(P.chain_buf + ((size_t)lpix * spp + s) * P.att_words);
+                        for (uint32_t w = 0; w < nw; w += 4u) {
+                            const uint32_t* row = lds_att + w * blockDim.x + threadIdx.x;
+                            dst[w >> 2] = make_uint4(row[0], row[blockDim.x], row[2u * blockDim.x], row[3u * blockDim.x]);
+                        }
+                    }
+                } else {
                 color = att_apply(color, run_h, run_n);
                 if (!BIG) {
                     const uint32_t full = natt >> 2; // whole windows that went to HBM; the rest is still in LDS
@@ -725,6 +759,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                         color = att_apply(color, h, n);
                     }
                 }
+                }
                 ended = true;
                 PF_MARK(14);
             }
@@ -737,7 +772,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                     // one 16-byte record per sample, stored as soon as the sample is finished.  (Round 1 kept an even sample in
                     // three registers until its odd partner could leave with it as one 32-byte sector: half the write-backs at
                     // the fabric, but the path is not bound by HBM and the registers are worth more.)
-                    P.sample_buf[(size_t)lpix * spp + s] = make_float4(color.x, color.y, color.z, 0.0f);
+                    // (.w: 0, or in MODE 4 the length of the chain the resolve pass still has to multiply into the sky colour)
+                    const uint32_t pending = (PACKED && t.best == ~0u) ? natt : 0u;
+                    P.sample_buf[(size_t)lpix * spp + s] = make_float4(color.x, color.y, color.z, __uint_as_float(pending));
                 } else {
                     sum = vadd(sum, color);
                 }
@@ -799,38 +836,76 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
 
 // Ordered resolve of the sample-chunk split: pixel_color += sample, s = 0 .. spp-1, exactly the sequential fp32 sum of
 // raytrace_pixel (core.cc:260-263), then * pixels_sample_scale and RGBAColor (core.cc:264, color.hpp:30-36).
-__global__ void __launch_bounds__(256) rtmi_resolve_kernel(const float4* __restrict__ sample_buf, uint32_t n_pixels,
-                                                           uint32_t spp, float scale, float* __restrict__ out_rgb,
-                                                           uint32_t* __restrict__ out_rgba) {
+// CHAIN: a record whose .w is nonzero holds the sky colour of a path and the length of its attenuation chain; the chain
+// (material handles, first bounce first, `bits` wide, `epw` per word) is multiplied in innermost-first here, which is
+// compute_color's A1 * (A2 * (... * sky)) (core.cc:247-248) bit for bit.  Albedos come from LDS.
+struct ResolveArgs {
+    const float4* sample_buf;
+    const uint32_t* chain_buf;
+    const uint4* mats;
+    uint32_t n_mats, bits, epw, words;
+    FastDiv div_epw;
+    uint32_t n_pixels, spp;
+    float scale;
+    float* out_rgb;
+    uint32_t* out_rgba;
+};
+template <bool CHAIN>
+__global__ void __launch_bounds__(256) rtmi_resolve_kernel(const ResolveArgs A) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    uint4* lds_mats = reinterpret_cast<uint4*>(lds_raw);
+    if (CHAIN) {
+        for (uint32_t i = threadIdx.x; i < A.n_mats; i += blockDim.x) lds_mats[i] = A.mats[i];
+        __syncthreads();
+    }
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pixels) return;
-    const float4* src = sample_buf + (size_t)p * spp;
+    if (p >= A.n_pixels) return;
+    const uint32_t spp = A.spp;
+    const float4* src = A.sample_buf + (size_t)p * spp;
     V3 sum = mk(0.0f, 0.0f, 0.0f);
+    auto finish = [&](const float4 c, uint32_t k) -> V3 {
+        V3 color = mk(c.x, c.y, c.z);
+        const uint32_t n = __float_as_uint(c.w);
+        if (CHAIN && n != 0u) {
+            const uint32_t* ch = A.chain_buf + ((size_t)p * spp + k) * A.words;
+            const uint32_t mask = (1u << A.bits) - 1u; // (bits <= 16)
+            uint32_t wi = fdiv(n - 1u, A.div_epw), j = (n - 1u) - wi * A.epw; // position of the last handle
+            uint32_t word = ch[wi];
+            for (uint32_t i = n; i != 0u; --i) {
+                const uint4 m0 = lds_mats[(word >> (j * A.bits)) & mask];
+                color = vmul(mk(__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z)), color);
+                if (j == 0u) {
+                    if (i > 1u) word = ch[--wi];
+                    j = A.epw - 1u;
+                } else {
+                    --j;
+                }
+            }
+        }
+        return color;
+    };
     uint32_t k = 0;
     for (; k + 4u <= spp; k += 4u) { // a whole 64-byte line per lane and trip
         const float4 c0 = src[k], c1 = src[k + 1u], c2 = src[k + 2u], c3 = src[k + 3u];
-        sum = vadd(sum, mk(c0.x, c0.y, c0.z));
-        sum = vadd(sum, mk(c1.x, c1.y, c1.z));
-        sum = vadd(sum, mk(c2.x, c2.y, c2.z));
-        sum = vadd(sum, mk(c3.x, c3.y, c3.z));
+        sum = vadd(sum, finish(c0, k));
+        sum = vadd(sum, finish(c1, k + 1u));
+        sum = vadd(sum, finish(c2, k + 2u));
+        sum = vadd(sum, finish(c3, k + 3u));
     }
-    for (; k < spp; ++k) {
-        const float4 c = src[k];
-        sum = vadd(sum, mk(c.x, c.y, c.z));
+    for (; k < spp; ++k) sum = vadd(sum, finish(src[k], k));
+    const V3 outc = vscale(sum, A.scale);
+    if (A.out_rgb) {
+        A.out_rgb[3u * p + 0u] = outc.x;
+        A.out_rgb[3u * p + 1u] = outc.y;
+        A.out_rgb[3u * p + 2u] = outc.z;
     }
-    const V3 outc = vscale(sum, scale);
-    if (out_rgb) {
-        out_rgb[3u * p + 0u] = outc.x;
-        out_rgb[3u * p + 1u] = outc.y;
-        out_rgb[3u * p + 2u] = outc.z;
-    }
-    if (out_rgba) {
+    if (A.out_rgba) {
         auto ch = [](float v) -> uint32_t {
             const float g = v > 0.0f ? __builtin_sqrtf(v) : 0.0f;
             const float c = g < 0.0f ? 0.0f : (g > 0.999f ? 0.999f : g);
             return (uint32_t)(uint8_t)(c * 256.0f);
         };
-        out_rgba[p] = ch(outc.x) | (ch(outc.y) << 8) | (ch(outc.z) << 16) | (255u << 24);
+        A.out_rgba[p] = ch(outc.x) | (ch(outc.y) << 8) | (ch(outc.z) << 16) | (255u << 24);
     }
 }
 
@@ -898,6 +973,11 @@ struct rtmi_scene {
     size_t staging_pixels = 0;
     float4* d_samples = nullptr; // sample-chunk split: [pixel][sample]
     size_t samples_capacity = 0; // records
+    // packed attenuation chains (MODE 4): eligible when the per-lane strings fit the LDS next to the staged scene
+    bool packed_ok = false;
+    uint32_t att_bits = 0, att_epw = 0, att_words = 0; // bits per handle, handles per word, words per sample (multiple of 4)
+    uint32_t* d_chain = nullptr;  // [pixel][sample][att_words]
+    size_t chain_capacity = 0;    // samples
     uint32_t chunk = ~0u;        // samples per work item of the split; ~0u: chosen per launch, 0: split off
     size_t sample_buf_cap_bytes = (size_t)24 << 30; // above this the split is off and a lane owns a whole pixel
     // HIP events around the trace kernel of every band of the most recent call (a banded call interleaves trace and
@@ -939,11 +1019,16 @@ KernelFn pick_variant(bool stats, bool big) {
     return stats ? rtmi_trace_kernel<ACCEL, true, false, MODE> : rtmi_trace_kernel<ACCEL, false, false, MODE>;
 }
 
-// whole_pixels: work items are whole pixels (no sample-record buffer): MODE 3, the lane keeps the pixel's sum
-KernelFn pick_kernel(uint32_t accel, bool stats, bool big, bool whole_pixels) {
-    if (whole_pixels)
-        return accel == RTMI_ACCEL_BVH ? pick_variant<RTMI_ACCEL_BVH, 3>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE, 3>(stats, big);
-    return accel == RTMI_ACCEL_BVH ? pick_variant<RTMI_ACCEL_BVH, 0>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE, 0>(stats, big);
+// mode 3: work items are whole pixels (no sample-record buffer), the lane keeps the pixel's sum; mode 4: sample records
+// with packed attenuation chains (LDS-resident scenes only); mode 0: sample records, run-length encoded chains
+KernelFn pick_kernel(uint32_t accel, bool stats, bool big, int mode) {
+    const bool bvh = accel == RTMI_ACCEL_BVH;
+    if (mode == 3) return bvh ? pick_variant<RTMI_ACCEL_BVH, 3>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE, 3>(stats, big);
+    if (mode == 4 && !big) {
+        if (bvh) return stats ? rtmi_trace_kernel<RTMI_ACCEL_BVH, true, false, 4> : rtmi_trace_kernel<RTMI_ACCEL_BVH, false, false, 4>;
+        return stats ? rtmi_trace_kernel<RTMI_ACCEL_BRUTE, true, false, 4> : rtmi_trace_kernel<RTMI_ACCEL_BRUTE, false, false, 4>;
+    }
+    return bvh ? pick_variant<RTMI_ACCEL_BVH, 0>(stats, big) : pick_variant<RTMI_ACCEL_BRUTE, 0>(stats, big);
 }
 
 void free_scene(rtmi_scene* s) {
@@ -959,6 +1044,7 @@ void free_scene(rtmi_scene* s) {
     hipFree(s->d_rgb);
     hipFree(s->d_rgba);
     hipFree(s->d_samples);
+    hipFree(s->d_chain);
     hipFree(s->d_wf_error);
     for (hipEvent_t e : s->ev_trace) hipEventDestroy(e);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -1063,6 +1149,28 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
             P.sample_buf = s->d_samples;
         }
     }
+    // packed chains travel with the sample records: att_words words per sample next to the 16-byte record
+    int mode = P.sample_buf ? 0 : 3;
+    if (P.sample_buf && s->packed_ok &&
+        (sample_floats * (sizeof(float4) + (size_t)s->att_words * 4u)) <= s->sample_buf_cap_bytes) {
+        if (sample_floats > s->chain_capacity) {
+            hipFree(s->d_chain);
+            s->d_chain = nullptr;
+            s->chain_capacity = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&s->d_chain), sample_floats * (size_t)s->att_words * 4u) == hipSuccess) {
+                s->chain_capacity = sample_floats;
+            } else {
+                (void)hipGetLastError(); // no room: the run-length encoded chains of mode 0 instead
+            }
+        }
+        if (s->d_chain) {
+            mode = 4;
+            P.att_bits = s->att_bits;
+            P.att_epw = s->att_epw;
+            P.att_words = s->att_words;
+            P.chain_buf = s->d_chain;
+        }
+    }
     const uint64_t n_work = (uint64_t)P.tiles_x * ((n_local_rows + 7u) / 8u) * 64u * P.n_chunks;
     if (n_work > 0xffffffffull) {
         set_error("rtmi: image too large for one launch");
@@ -1109,15 +1217,32 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         if (rc != RTMI_OK) return rc;
 #endif
     } else {
-        KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big, P.sample_buf == nullptr);
+        KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big, mode);
         void* args[] = {&P};
         HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
     }
     HIP_TRY(hipEventRecord(s->ev_trace[2u * band + 1u], stream));
     if (P.sample_buf) {
-        const uint32_t n_pixels = n_local_rows * W;
-        hipLaunchKernelGGL(rtmi_resolve_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, P.sample_buf,
-                           n_pixels, spp, s->cam.pixels_sample_scale, d_rgb, d_rgba);
+        ResolveArgs A{};
+        A.sample_buf = P.sample_buf;
+        A.n_pixels = n_local_rows * W;
+        A.spp = spp;
+        A.scale = s->cam.pixels_sample_scale;
+        A.out_rgb = d_rgb;
+        A.out_rgba = d_rgba;
+        const dim3 rgrid((A.n_pixels + 255u) / 256u);
+        if (mode == 4 && !use_wf) {
+            A.chain_buf = P.chain_buf;
+            A.mats = s->d_mats;
+            A.n_mats = s->n_mats;
+            A.bits = s->att_bits;
+            A.epw = s->att_epw;
+            A.words = s->att_words;
+            A.div_epw = make_fastdiv(s->att_epw);
+            hipLaunchKernelGGL(rtmi_resolve_kernel<true>, rgrid, dim3(256), (size_t)s->n_mats * sizeof(uint4), stream, A);
+        } else {
+            hipLaunchKernelGGL(rtmi_resolve_kernel<false>, rgrid, dim3(256), 0, stream, A);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (last) {
@@ -1148,7 +1273,7 @@ int check_watchdog(rtmi_scene* s) {
 int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks,
            uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream) {
     const uint32_t H = s->cam.img_height, W = s->cam.img_width;
-    const uint64_t row_bytes = (uint64_t)W * s->cam.samples_per_pixel * sizeof(float4);
+    const uint64_t row_bytes = (uint64_t)W * s->cam.samples_per_pixel * (sizeof(float4) + (s->packed_ok ? (size_t)s->att_words * 4u : 0u));
     const uint64_t cap = s->sample_buf_cap_bytes;
     const uint64_t max_rows = row_bytes ? cap / row_bytes : 0;
     const bool split_on = s->chunk != 0u && s->cam.samples_per_pixel > 4u;
@@ -1330,7 +1455,23 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     off += s->stack_depth * s->block * (s->big ? 4u : 2u);
     off = align16(off);
     s->lds_att = off;
-    if (!s->big) off += kAttLds * s->block * 4u;
+    if (!s->big) {
+        // packed attenuation chains when the strings of all lanes fit what the scene leaves of the 80 KiB (two workgroups per
+        // CU): ceil(log2 n_materials) bits per bounce, no handle straddling a word, a multiple of four words per lane
+        uint32_t bits = 1;
+        while ((1u << bits) < n_materials) ++bits;
+        const uint32_t epw = 32u / bits;
+        const uint32_t words = ((std::max<uint32_t>(1u, camera->maxdepth) + epw - 1u) / epw + 3u) & ~3u;
+        const uint64_t with_packed = (uint64_t)off + (uint64_t)words * s->block * 4u + (s->block / 64u) * 80u + 16u;
+        s->packed_ok = tune.chain_mode != 1 && bits <= 16u && words <= 255u && with_packed <= 80u * 1024u &&
+                       (uint64_t)n_materials * sizeof(uint4) <= 64u * 1024u;
+        if (s->packed_ok) {
+            s->att_bits = bits;
+            s->att_epw = epw;
+            s->att_words = words;
+        }
+        off += std::max(kAttLds, s->packed_ok ? words : 0u) * s->block * 4u;
+    }
     s->lds_pool = off; // per wave: {work_next, work_end, slot_next, slot_end}
     off += (s->block / 64u) * 80u; // + 64-byte rank table of coop_draws
     s->lds_bytes = align16(off);
@@ -1429,11 +1570,15 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     }
 
     // persistent grid: exactly as many workgroups as the device keeps resident
-    KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big, false);
+    KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big, 0);
     HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)s->lds_bytes));
-    HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s->accel, s->collect_stats, s->big, true)),
+    HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s->accel, s->collect_stats, s->big, 3)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    if (s->packed_ok) {
+        HIP_TRY_S(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_kernel(s->accel, s->collect_stats, s->big, 4)),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    }
     int per_cu = 0;
     HIP_TRY_S(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)s->block, s->lds_bytes));
     if (per_cu < 1) {
@@ -1655,6 +1800,7 @@ extern "C" int rtmi_scene_get_launch_info(const rtmi_scene* s, rtmi_launch_info*
     out->scene_in_lds = s->big ? 0u : 1u;
     out->stack_depth = s->stack_depth;
     out->whole_pixel_fallbacks = s->whole_pixel_fallbacks;
+    out->packed_chains = s->packed_ok ? s->att_words : 0u;
     return RTMI_OK;
 }
 

@@ -61,6 +61,11 @@ struct RtmiLaunch {
     uint32_t* out_rgba;
     uint32_t* work_counter;
     uint32_t* att_stack; // [lane][maxdepth] {handle, count}: attenuation runs that did not fit LDS
+    // packed attenuation chains (MODE 4): every non-dielectric bounce appends its material handle, att_bits wide, to a
+    // per-lane bit string in LDS (att_epw handles per 32-bit word, none straddling); a path that reaches the sky copies
+    // its string to chain_buf[pixel][sample] (att_words words, a multiple of 4) and rtmi_resolve_kernel multiplies
+    uint32_t att_bits, att_epw, att_words;
+    uint32_t* chain_buf;
     unsigned long long* stats; // {samples, segments, sphere_tests, node_tests}
     // queue-scheduled kernel (rtmi_wavefront.hip): path slots, rings and control words in LDS
     uint32_t wf_slots;      // path slots per workgroup

@@ -181,6 +181,49 @@ def test_scheduling_knobs_do_not_change_the_image(pkg, ob, rtow, gpu):
         assert st["samples"] == cam.img_width * cam.img_height * 96, env
 
 
+def test_packed_and_run_length_attenuation_chains(pkg, ob, rtow, gpu):
+    """The attenuation chain of a path (core.cc:247-248 multiplies innermost-first) has two forms: packed material handles
+    in LDS that leave with the sample record and are multiplied by the resolve pass (scenes whose strings fit: the box of
+    config 5, anything with a low bounce limit), and run-length encoded runs multiplied at path end (RTOW at 50 bounces).
+    Both give the oracle's frame bit for bit: whole calls, banded calls, sharded row blocks, whole-pixel work items."""
+    torch = gpu
+    g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
+    ccam = pkg.camera_setup(pkg.camera_params(**json.loads(str(g["camera"]))))
+    for tun, packed in ((None, True), (dict(chain_mode=1), False), (dict(sample_buf_mb=1), True), (dict(chunk_samples=-1), True),
+                        (dict(block_lanes=512, chunk_samples=5), True)):
+        for accel, _ in _both(pkg):
+            with pkg.Scene(ccam, g["objects"], g["materials"], accel=accel, tuning=tun) as s:
+                assert (s.launch_info()["packed_chains"] > 0) == packed
+                rgb, rgba = s.render_rows(0, ccam.img_height, int(g["seed"]))
+                part, _ = s.render_rows(7, 19, int(g["seed"]))
+            _assert_frames_equal(rgb, g["rgb"])
+            assert np.array_equal(rgba, g["rgba"])
+            _assert_frames_equal(part, g["rgb"][7:19])
+    # RTOW: 488 materials = 9 bits a bounce; packed at 12 bounces, run-length encoded at 50
+    for depth, packed in ((12, True), (50, False)):
+        kw = dict(image_width=112, samples_per_pixel=10, max_depth=depth)
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        want, want8 = ob.render_rect_counter(ocam, *rtow, 8, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
+        for tun in (None, dict(chain_mode=1)):
+            with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=tun) as s:
+                assert (s.launch_info()["packed_chains"] > 0) == (packed and tun is None)
+                rgb, rgba = s.render_rows(0, cam.img_height, 8)
+                # sharded row blocks through the device-pointer entry (three ranks' worth on one device)
+                dev = torch.device("cuda", 0)
+                plan = pkg.RowShardPlan(cam.img_height, 8, 3)
+                parts = []
+                for r in range(3):
+                    y_first, n_blocks, rows = plan.shard(r)
+                    buf = torch.zeros((plan.max_rows, cam.img_width, 3), dtype=torch.float32, device=dev)
+                    s.render_row_blocks_device(y_first, 8, 3, n_blocks, 8, buf.data_ptr(), 0, torch.cuda.current_stream(dev).cuda_stream)
+                    torch.cuda.synchronize()
+                    parts.append(buf)
+                frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev)).cpu().numpy()
+            _assert_frames_equal(rgb, want)
+            assert np.array_equal(rgba, want8)
+            _assert_frames_equal(frame, want)
+
+
 def test_random_scenes_and_cameras(pkg, ob, gpu):
     """Forty random worlds -- overlapping and nested spheres, cameras inside spheres, fuzz > 1 (clamped at
     construction), refraction indices below 1, huge and tiny radii, shared material handles -- through both accel

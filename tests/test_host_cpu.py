@@ -84,7 +84,7 @@ def test_scene_create_argument_errors(pkg):
     info = pkg.LaunchInfo()
     info.struct_size = C.sizeof(pkg.LaunchInfo)
     assert pkg.lib().rtmi_scene_get_launch_info(None, C.byref(info)) == pkg.RTMI_ERR_BAD_ARG
-    assert C.sizeof(pkg.LaunchInfo) == 36
+    assert C.sizeof(pkg.LaunchInfo) == 40
     pkg.lib().rtmi_scene_destroy(None)  # no-op
 
 
