@@ -836,9 +836,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
 
 // Ordered resolve of the sample-chunk split: pixel_color += sample, s = 0 .. spp-1, exactly the sequential fp32 sum of
 // raytrace_pixel (core.cc:260-263), then * pixels_sample_scale and RGBAColor (core.cc:264, color.hpp:30-36).
-// CHAIN: a record whose .w is nonzero holds the sky colour of a path and the length of its attenuation chain; the chain
-// (material handles, first bounce first, `bits` wide, `epw` per word) is multiplied in innermost-first here, which is
-// compute_color's A1 * (A2 * (... * sky)) (core.cc:247-248) bit for bit.  Albedos come from LDS.
+// One lane per pixel, 64 bytes per lane and trip: HBM-bound (5.2 TB/s at 1080p x 512 spp).
+struct ResolveArgs;
+DEV void resolve_store(const ResolveArgs& A, uint32_t p, V3 sum);
 struct ResolveArgs {
     const float4* sample_buf;
     const uint32_t* chain_buf;
@@ -850,49 +850,7 @@ struct ResolveArgs {
     float* out_rgb;
     uint32_t* out_rgba;
 };
-template <bool CHAIN>
-__global__ void __launch_bounds__(256) rtmi_resolve_kernel(const ResolveArgs A) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    uint4* lds_mats = reinterpret_cast<uint4*>(lds_raw);
-    if (CHAIN) {
-        for (uint32_t i = threadIdx.x; i < A.n_mats; i += blockDim.x) lds_mats[i] = A.mats[i];
-        __syncthreads();
-    }
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.n_pixels) return;
-    const uint32_t spp = A.spp;
-    const float4* src = A.sample_buf + (size_t)p * spp;
-    V3 sum = mk(0.0f, 0.0f, 0.0f);
-    auto finish = [&](const float4 c, uint32_t k) -> V3 {
-        V3 color = mk(c.x, c.y, c.z);
-        const uint32_t n = __float_as_uint(c.w);
-        if (CHAIN && n != 0u) {
-            const uint32_t* ch = A.chain_buf + ((size_t)p * spp + k) * A.words;
-            const uint32_t mask = (1u << A.bits) - 1u; // (bits <= 16)
-            uint32_t wi = fdiv(n - 1u, A.div_epw), j = (n - 1u) - wi * A.epw; // position of the last handle
-            uint32_t word = ch[wi];
-            for (uint32_t i = n; i != 0u; --i) {
-                const uint4 m0 = lds_mats[(word >> (j * A.bits)) & mask];
-                color = vmul(mk(__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z)), color);
-                if (j == 0u) {
-                    if (i > 1u) word = ch[--wi];
-                    j = A.epw - 1u;
-                } else {
-                    --j;
-                }
-            }
-        }
-        return color;
-    };
-    uint32_t k = 0;
-    for (; k + 4u <= spp; k += 4u) { // a whole 64-byte line per lane and trip
-        const float4 c0 = src[k], c1 = src[k + 1u], c2 = src[k + 2u], c3 = src[k + 3u];
-        sum = vadd(sum, finish(c0, k));
-        sum = vadd(sum, finish(c1, k + 1u));
-        sum = vadd(sum, finish(c2, k + 2u));
-        sum = vadd(sum, finish(c3, k + 3u));
-    }
-    for (; k < spp; ++k) sum = vadd(sum, finish(src[k], k));
+DEV void resolve_store(const ResolveArgs& A, uint32_t p, V3 sum) {
     const V3 outc = vscale(sum, A.scale);
     if (A.out_rgb) {
         A.out_rgb[3u * p + 0u] = outc.x;
@@ -906,6 +864,91 @@ __global__ void __launch_bounds__(256) rtmi_resolve_kernel(const ResolveArgs A) 
             return (uint32_t)(uint8_t)(c * 256.0f);
         };
         A.out_rgba[p] = ch(outc.x) | (ch(outc.y) << 8) | (ch(outc.z) << 16) | (255u << 24);
+    }
+}
+
+__global__ void __launch_bounds__(256) rtmi_resolve_kernel(const ResolveArgs A) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.n_pixels) return;
+    const uint32_t spp = A.spp;
+    const float4* src = A.sample_buf + (size_t)p * spp;
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    uint32_t k = 0;
+    for (; k + 4u <= spp; k += 4u) { // a whole 64-byte line per lane and trip
+        const float4 c0 = src[k], c1 = src[k + 1u], c2 = src[k + 2u], c3 = src[k + 3u];
+        sum = vadd(sum, mk(c0.x, c0.y, c0.z));
+        sum = vadd(sum, mk(c1.x, c1.y, c1.z));
+        sum = vadd(sum, mk(c2.x, c2.y, c2.z));
+        sum = vadd(sum, mk(c3.x, c3.y, c3.z));
+    }
+    for (; k < spp; ++k) {
+        const float4 c = src[k];
+        sum = vadd(sum, mk(c.x, c.y, c.z));
+    }
+    resolve_store(A, p, sum);
+}
+
+// The resolve pass of MODE 4 launches: a record whose .w is nonzero holds the sky colour of a path and the length of its
+// attenuation chain; the chain (material handles, first bounce first, `bits` wide, `epw` per word, in chain_buf next to
+// the record) is multiplied in innermost-first, which is compute_color's A1 * (A2 * (... * sky)) (core.cc:247-248) bit
+// for bit.  A wave takes kResPix pixels at a time: for each of them its lanes load 64 consecutive samples (records and
+// chain slots are contiguous across the lanes: coalesced, where one lane per pixel would touch 64 B per sample in 64
+// different lines) and multiply their chains in parallel -- a chain is serial, the samples are not; the colours go to an
+// LDS tile and lanes 0 .. kResPix-1 add their pixel's 64 colours up in sample order (core.cc:260-263).  Albedos in LDS.
+constexpr uint32_t kResPix = 8, kResRow = 65; // (65: the summing lanes read one column, a power-of-two row stride would put them in one bank)
+__global__ void __launch_bounds__(256) rtmi_resolve_chain_kernel(const ResolveArgs A) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    uint4* lds_mats = reinterpret_cast<uint4*>(lds_raw);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
+    float4* tile = reinterpret_cast<float4*>(lds_raw + (((size_t)A.n_mats * sizeof(uint4) + 15u) & ~(size_t)15u)) + (size_t)wave * kResPix * kResRow;
+    for (uint32_t i = threadIdx.x; i < A.n_mats; i += blockDim.x) lds_mats[i] = A.mats[i];
+    __syncthreads();
+    const uint32_t spp = A.spp, mask = (1u << A.bits) - 1u; // (bits <= 16)
+    const uint32_t n_groups = (A.n_pixels + kResPix - 1u) / kResPix;
+    for (uint32_t g = blockIdx.x * n_waves + wave; g < n_groups; g += gridDim.x * n_waves) {
+        const uint32_t p0 = g * kResPix, np = min(kResPix, A.n_pixels - p0);
+        V3 sum = mk(0.0f, 0.0f, 0.0f); // lanes < np: the running sum of pixel p0 + lane
+        for (uint32_t b = 0; b < spp; b += 64u) {
+            const uint32_t cnt = min(64u, spp - b);
+            for (uint32_t q = 0; q < np; ++q) {
+                if (lane < cnt) {
+                    const size_t rec = (size_t)(p0 + q) * spp + b + lane;
+                    const float4 c = A.sample_buf[rec];
+                    V3 color = mk(c.x, c.y, c.z);
+                    const uint32_t n = __float_as_uint(c.w);
+                    if (n != 0u) {
+                        const uint4* ch = reinterpret_cast<const uint4*>(A.chain_buf + rec * A.words);
+                        uint32_t wi = fdiv(n - 1u, A.div_epw), j = (n - 1u) - wi * A.epw; // position of the last handle
+                        uint4 grp = ch[wi >> 2];
+                        auto pick = [&](uint32_t w) { const uint32_t s_ = w & 3u; return s_ == 0u ? grp.x : (s_ == 1u ? grp.y : (s_ == 2u ? grp.z : grp.w)); };
+                        uint32_t word = pick(wi);
+                        for (uint32_t i = n; i != 0u; --i) {
+                            const uint4 m0 = lds_mats[(word >> (j * A.bits)) & mask];
+                            color = vmul(mk(__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z)), color);
+                            if (j == 0u) {
+                                if (i > 1u) {
+                                    if ((wi & 3u) == 0u) grp = ch[(wi - 1u) >> 2];
+                                    word = pick(--wi);
+                                }
+                                j = A.epw - 1u;
+                            } else {
+                                --j;
+                            }
+                        }
+                    }
+                    tile[q * kResRow + lane] = make_float4(color.x, color.y, color.z, 0.0f);
+                }
+            }
+            // (a wave's LDS accesses are ordered: no barrier between the phases of one wave)
+            if (lane < np) {
+                const float4* row = tile + lane * kResRow;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const float4 c = row[i];
+                    sum = vadd(sum, mk(c.x, c.y, c.z));
+                }
+            }
+        }
+        if (lane < np) resolve_store(A, p0 + lane, sum);
     }
 }
 
@@ -1239,9 +1282,14 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
             A.epw = s->att_epw;
             A.words = s->att_words;
             A.div_epw = make_fastdiv(s->att_epw);
-            hipLaunchKernelGGL(rtmi_resolve_kernel<true>, rgrid, dim3(256), (size_t)s->n_mats * sizeof(uint4), stream, A);
+            const size_t lds = (((size_t)s->n_mats * sizeof(uint4) + 15u) & ~(size_t)15u) + 4u * kResPix * kResRow * sizeof(float4);
+            const uint32_t groups = (A.n_pixels + kResPix - 1u) / kResPix;
+            const uint32_t blocks = std::min<uint32_t>((groups + 3u) / 4u, s->n_cus * 8u);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rtmi_resolve_chain_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(rtmi_resolve_chain_kernel, dim3(std::max(1u, blocks)), dim3(256), lds, stream, A);
         } else {
-            hipLaunchKernelGGL(rtmi_resolve_kernel<false>, rgrid, dim3(256), 0, stream, A);
+            hipLaunchKernelGGL(rtmi_resolve_kernel, rgrid, dim3(256), 0, stream, A);
         }
         HIP_TRY(hipGetLastError());
     }

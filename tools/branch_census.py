@@ -54,8 +54,9 @@ if "--build" in sys.argv:
     print("built", prof_lib, static_json)
     sys.exit(0)
 
-w, spp = int(sys.argv[1]), int(sys.argv[2])
-which = sys.argv[3] if len(sys.argv) > 3 else "rtow"
+pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+w, spp = int(pos[0]), int(pos[1])
+which = pos[2] if len(pos) > 2 else "rtow"
 if which == "grid":
     objs, mats, kw = pkg.workloads.big_grid(316)
     kw.update(image_width=w, samples_per_pixel=spp)
@@ -70,7 +71,7 @@ v = [0] * 128
 for lib_path in (prof_lib, census_lib):
     pkg._lib = None
     pkg.LIB_PATH = lib_path
-    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as sc:
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BRUTE if '--brute' in sys.argv else pkg.ACCEL_BVH) as sc:
         sc.render_rows(0, cam.img_height, 7)
         if lib_path == prof_lib:
             ms = sc.last_kernel_ms()
