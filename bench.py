@@ -104,7 +104,8 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=0, help="override the config's image width (diagnostics)")
     ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel (diagnostics)")
     ap.add_argument("--depth", type=int, default=0, help="override the config's bounce limit (diagnostics)")
-    ap.add_argument("--accel", choices=("bvh", "brute"), default="bvh")
+    ap.add_argument("--accel", choices=("auto", "bvh", "brute"), default="auto",
+                    help="auto = the library's own choice (RTMI_ACCEL_AUTO: BVH walk above 24 spheres, the reference's linear scan below)")
     ap.add_argument("--single-process", action="store_true",
                     help="one process, N devices, through rtmi_frame_* (RCCL inside librtmi.so)")
     ap.add_argument("--force-dist", action="store_true",
@@ -260,6 +261,10 @@ def main(argv=None):
     kw, objs, mats, label = workload(pkg, cfg, args)
     cam = pkg.camera_setup(pkg.camera_params(**kw))
     W, H, spp, depth = cam.img_width, cam.img_height, cam.samples_per_pixel, cam.maxdepth
+    # RTMI_ACCEL_AUTO's rule, restated so that the label is known before the scene exists: the walk overtakes the scan
+    # between 20 and 30 spheres (tools/scan_crossover.py; the 7-sphere box of config 5 is 1.3x faster scanned)
+    if args.accel == "auto":
+        args.accel = "bvh" if len(objs) > 24 else "brute"
     accel = pkg.ACCEL_BVH if args.accel == "bvh" else pkg.ACCEL_BRUTE
     samples = W * H * spp
 

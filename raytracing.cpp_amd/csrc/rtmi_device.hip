@@ -626,6 +626,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
         ISA_MARK("shade");
         PF_MARK(7);
         PB(8, phase == PH_SHADE);
+        PB(9, phase == PH_SHADE && t.best < kBlackSample);
+        PB(14, phase == PH_SHADE && t.best == ~0u);
+        PB(15, phase == PH_SHADE && t.best == ~0u && (natt != 0u || run_n != 0u));
         PB(22, rq == RQ_WORD || (phase == PH_SHADE && t.best == ~0u)); // the shared normalize(ray.direction)
         if (phase == PH_SHADE) {
             bool ended = false;
@@ -640,7 +643,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             } else if (t.best != ~0u) {
                 ISA_MARK("shade-hit-record");
                 PF_MARK(8);
-                PB(9, true);
                 // IntersectionRecord for the winning sphere, object.defs.cc:62-65 and :11-18
                 const uint4 sraw = lds_spheres[t.best];
                 const uint4 araw = lds_aux[t.best];
@@ -717,8 +719,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             } else {
                 ISA_MARK("shade-miss");
                 PF_MARK(8);
-                PB(14, true);
-                PB(15, natt != 0u || run_n != 0u);
                 // miss: sky gradient (core.cc:254-256), then the attenuations innermost-first (core.cc:247-248)
                 const float tt = 0.5f * (unit_dir.y + 1.0f);
                 color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
@@ -1422,7 +1422,9 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     s->collect_stats = opt.collect_stats != 0;
     s->n_objects = n_objects;
     s->n_mats = n_materials;
-    s->accel = opt.accel == RTMI_ACCEL_AUTO ? (n_objects > 8 ? RTMI_ACCEL_BVH : RTMI_ACCEL_BRUTE) : opt.accel;
+    // (the walk overtakes the scan between 20 and 30 spheres: tools/scan_crossover.py on MI355X, random scenes of 4 .. 61
+    // spheres: 1.03-1.09x slower up to 21, 0.95x at 29, 0.73x at 61; the 7-sphere box of config 5 is 1.30x slower walked)
+    s->accel = opt.accel == RTMI_ACCEL_AUTO ? (n_objects > 24 ? RTMI_ACCEL_BVH : RTMI_ACCEL_BRUTE) : opt.accel;
     if (n_objects == 0) s->accel = RTMI_ACCEL_BRUTE; // an empty world has no tree; the scan over zero spheres misses
     if (s->accel != RTMI_ACCEL_BVH && s->accel != RTMI_ACCEL_BRUTE) {
         set_error("rtmi_scene_create: unknown accel");
