@@ -436,9 +436,8 @@ def main(argv=None):
             frame_h = frame.cpu().numpy()
             xs, ys = rng.integers(0, W, n_chk), rng.integers(0, H, n_chk)
             obvh = None
-            if len(objs) > 4096:  # the oracle's own linear scan over 100k spheres takes minutes per pixel: walk the BVH
-                obvh = pkg.bvh_build(objs)
-                obvh = dict(obvh, nodes=obvh["nodes"].view(ob.BVH_NODE_DTYPE))
+            if len(objs) > 4096:  # the oracle's own linear scan over 100k spheres takes minutes per pixel: walk the tree
+                obvh = pkg.bvh4_build(objs)
             worst = 0.0
             for x, y in zip(xs, ys):
                 want, _ = ob.render_rect_counter(ocam, objs, mats, RENDER_SEED, int(x), int(y), int(x) + 1, int(y) + 1,
@@ -448,11 +447,15 @@ def main(argv=None):
                 worst = max(worst, float(d.max()))
             out["parity_check"] = {"pixels": n_chk, "max_abs_diff_vs_oracle": worst,
                                    "oracle": "linear scan" if obvh is None else "instrumented BVH walk (== linear scan, tests)"}
-        bvh = pkg.bvh_build(objs) if args.accel == "bvh" else None
-        if bvh is not None:
-            bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
+        # the tree the kernel walks: binary for LDS-resident scenes, the 4-wide one with quantised boxes for HBM-resident ones
+        bvh = None
+        if args.accel == "bvh":
+            in_lds = scene.launch_info()["scene_in_lds"] if scene is not None else len(objs) <= 600
+            bvh = pkg.bvh_build(objs) if in_lds else pkg.bvh4_build(objs)
+            if in_lds:
+                bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
         ctr_stride = 24
-        ctr = {"samples": 0, "segments": 0, "sphere_tests": 0, "node_tests": 0}
+        ctr = {"samples": 0, "segments": 0, "sphere_tests": 0, "node_tests": 0, "hit_lambertian": 0, "hit_metallic": 0}
         sub_spp = min(spp, 64)
         ccam = ob.camera_setup(ob.camera_params(**dict(kw, samples_per_pixel=sub_spp)))
         for y in range(ctr_stride // 2, H, ctr_stride):
@@ -462,6 +465,11 @@ def main(argv=None):
                 for k in ctr:
                     ctr[k] += c[k]
         fps = flops_per_sample(ctr)
+        chain_words = scene.launch_info()["packed_chains"] if scene is not None else 0
+        chain_bytes = 0.0
+        if chain_words:
+            bits = max(1, int(np.ceil(np.log2(max(2, len(mats))))))
+            chain_bytes = (ctr["hit_lambertian"] + ctr["hit_metallic"]) / ctr["samples"] * bits / 8.0
         kernel_s = max(per_rank_ms) / 1e3
         samples_per_launch = samples / n_gpus
         achieved = samples_per_launch * fps / kernel_s / 1e12
@@ -490,12 +498,15 @@ def main(argv=None):
             "traffic": traffic, "traffic_note": traffic_note,
             "kernel": "rtmi_trace_kernel<%s>" % args.accel, "kernel_ms": round(kernel_s * 1e3, 3),
             "flops_per_sample": round(fps, 1),
-            "counters_per_sample": {k: round(ctr[k] / ctr["samples"], 3) for k in ctr if k != "samples"},
+            "counters_per_sample": {k: round(ctr[k] / ctr["samples"], 3) for k in ctr if k not in ("samples", "hit_lambertian", "hit_metallic")},
             "counters_source": f"oracle instrumented walk, {ctr['samples']} samples on a uniform pixel subset",
             # scene staged once per workgroup-resident CU + 16-byte sample records written once (the ordered resolve
             # pass reads them back) + framebuffer slice; the path is VALU-bound, HBM is reported as a sanity check
-            "hbm_algorithmic_bytes_per_launch": int(len(objs) * (16 + 16 + 32) + (0 if bvh is None else len(bvh["nodes"]) * 64)
-                                                    + samples_per_launch * 16 + W * (H // n_gpus) * 16),
+            # + in packed-chain launches the material handles a path leaves for the resolve pass (its non-dielectric bounces x
+            # ceil(log2 n_materials) bits; the slot the launch reserves per sample is chain_words x 4 bytes)
+            "hbm_algorithmic_bytes_per_launch": int(len(objs) * (16 + 16 + 32) + (0 if bvh is None else len(bvh["nodes"]) * bvh["nodes"].dtype.itemsize)
+                                                    + samples_per_launch * (16 + chain_bytes) + W * (H // n_gpus) * 16),
+            "chain_words_per_sample": chain_words,
             "note": "fp32 VALU-bound path (SURVEY 8d): peak = non-FMA issue rate 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
         }
         # ---- the reference's own algorithm on the GPU: linear closest-hit scan on the same frame (or a uniform subset of

@@ -51,6 +51,10 @@ constexpr uint32_t kBlackSample = 0xfffffffeu; // Trav::best of a sample that is
 #define RTMI_WPE 6 // waves per SIMD the register allocation aims at (A/B: 7 = 72 VGPRs + 20 B of scratch, 4 % slower)
 #endif
 
+#ifndef RTMI_WPE_BIG
+#define RTMI_WPE_BIG 7 // HBM-resident scenes: two 896-lane workgroups per CU = 7 waves per SIMD = 72 VGPRs
+#endif
+
 #ifndef RTMI_ASM_WALK
 #define RTMI_ASM_WALK 1 // 0: the compiler's node step everywhere (the A/B and the fallback for a changed register budget)
 #endif
@@ -164,7 +168,7 @@ template <int ACCEL, bool STATS, bool BIG, int MODE>
 // SIMD (measured), and one register more would silently halve it -- hence the explicit bound
 // (HBM-resident scenes wait on their node reads, not on issue slots: their variants are allocated for 8 waves per SIMD --
 // 64 VGPRs, which they fit without spilling -- and run as two 896-lane workgroups per CU, 7 waves per SIMD: -3.4 %)
-__global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 : RTMI_WPE))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
+__global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE, BIG ? RTMI_WPE_BIG : RTMI_WPE))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
     // MODE 0: work items are chunks of a pixel's samples, one 16-byte record per sample; 3: whole-pixel work items (no
     // sample records: the lane adds its pixel's samples up itself); 4: as 0, with the attenuation chain as a packed string
     // of material handles in LDS that leaves with the sample record and is multiplied by the resolve pass (scenes whose
@@ -178,11 +182,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
     // signed: nodes >= 0, leaves < -1, the sentinel -1 (16-bit entries are read back sign-extended); t.sp is an LDS address
     using StackS = typename std::conditional<BIG, int32_t, int16_t>::type;
     typedef __attribute__((address_space(3))) StackS lds_stack_t;
-    constexpr uint32_t kStackEnd = 0xffffffffu;
+    // "not walking": the 16-bit walk keeps the popped sentinel (-1) there, the 4-wide walk of HBM-resident scenes its own
+    // reference encoding (rtmi_internal.h: node index < 2^24 - 1 | 0x80000000 + leaf group | kWalkDone4; stack sentinel 0)
+    constexpr uint32_t kStackEnd = BIG ? kWalkDone4 : 0xffffffffu;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8*)lds_raw;
     const uint32_t sp0 = lds0 + P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT), sp_stride = blockDim.x * (uint32_t)sizeof(StackT);
     auto stack_at = [](uint32_t addr) -> lds_stack_t* { return (lds_stack_t*)(uintptr_t)addr; };
-    if (ACCEL == RTMI_ACCEL_BVH) *stack_at(sp0) = (StackS)-1;
+    if (ACCEL == RTMI_ACCEL_BVH) *stack_at(sp0) = BIG ? (StackS)0 : (StackS)-1;
     uint32_t* lds_att = reinterpret_cast<uint32_t*>(lds_raw + P.lds_att);
     // per-wave pools: work indices are taken from the global counter 64 at a time (a single counter word saturates at
     // ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M work items)
@@ -300,9 +306,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
     };
     // the spheres of one leaf against the current segment, two at a time: both discriminants, then the (rare) roots.
     // The first pair is straight code -- with the default leaf size of 2 it is the whole leaf -- larger leaves loop on
-    auto test_leaf = [&](uint32_t ref) {
-        const uint32_t first = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
-        const uint32_t cnt = BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u);
+    auto test_slots = [&](uint32_t first, uint32_t cnt) {
         t.a = vdot(t.d, t.d); // (recomputed here: not a register across the node steps)
         const Recip ra = recip_for(t.a); // shared by every root of this leaf step
         auto pair = [&](uint32_t q) {
@@ -320,6 +324,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
             for (uint32_t q = 2u; q < cnt; q += 2u) pair(q);
         }
         if (STATS) st_sphere += cnt;
+    };
+    auto test_leaf = [&](uint32_t ref) { // a leaf reference: 24-bit slot + count (HBM-resident scenes), 13-bit slot + count - 1 (LDS)
+        test_slots(BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu), BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u));
     };
     auto begin_segment = [&](V3 o, V3 d) {
         t.o = o;
@@ -507,7 +514,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                     continue;
                 }
 #endif
-                const bool at_leaf = (int32_t)t.cur < -1, at_node = (int32_t)t.cur >= 0; // (inline constants)
+                // (16-bit walk: nodes >= 0, leaves < -1, inline constants; 4-wide walk: a leaf group has bit 31 set, a node index
+                // is below kWalkDone4)
+                const bool at_leaf = BIG ? (int32_t)t.cur < 0 : (int32_t)t.cur < -1;
+                const bool at_node = BIG ? t.cur < kWalkDone4 : (int32_t)t.cur >= 0;
                 const uint64_t m_leaf = ballot(at_leaf);
                 const uint64_t m_node = ballot(at_node);
 #if defined(RTMI_PROF) && RTMI_PROF == 1
@@ -524,17 +534,81 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                 if (n_leaf > n_node) {
                     PF_MARK(3);
                     if (at_leaf) {
-                        test_leaf(t.cur);
-                        pop = true;
+                        if (BIG) {
+                            // a leaf group: bits 0..22 first slot, 23..26 "two spheres" per leaf child, 27..30 the leaves still
+                            // to test (their boxes were hit); one leaf per trip, lowest first
+                            const uint32_t lm = (t.cur >> 27) & 15u, two = (t.cur >> 23) & 15u;
+                            const uint32_t i = (uint32_t)__builtin_ctz(lm);
+                            test_slots((t.cur & 0x007fffffu) + i + (uint32_t)__popc(two & ((1u << i) - 1u)), 1u + ((two >> i) & 1u));
+                            const uint32_t rest = lm & (lm - 1u);
+                            t.cur = (t.cur & ~(15u << 27)) | (rest << 27);
+                            pop = rest == 0u;
+                        } else {
+                            test_leaf(t.cur);
+                            pop = true;
+                        }
                     }
                     PF_MARK(21);
-                } else if (at_node) {
+                } else if (BIG && at_node) {
+                    // ---- 4-wide node, 48 bytes through L1 / L2 / Infinity Cache: three 16-byte reads for four boxes ----
+                    const uint4* np = lds_nodes + 3u * t.cur;
+                    const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
+                    // plane q of an axis sits at org + q * 2^e; in ray parameters t(q) = q * (2^e / d) + (org - o) / d, and the pad
+                    // (pinv = pad * |1/d|) moves near planes down, far planes up
+                    const float stx = __uint_as_float((q0.w & 0xffu) << 23) * t.inv.x;
+                    const float sty = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * t.inv.y;
+                    const float stz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * t.inv.z;
+                    const float bx = __builtin_fmaf(__uint_as_float(q0.x), t.inv.x, t.oinv.x);
+                    const float by = __builtin_fmaf(__uint_as_float(q0.y), t.inv.y, t.oinv.y);
+                    const float bz = __builtin_fmaf(__uint_as_float(q0.z), t.inv.z, t.oinv.z);
+                    const float bnx = bx - t.pinv.x, bfx = bx + t.pinv.x;
+                    const float bny = by - t.pinv.y, bfy = by + t.pinv.y;
+                    const float bnz = bz - t.pinv.z, bfz = bz + t.pinv.z;
+                    // a ray that runs down an axis enters through the high plane
+                    const bool ngx = t.inv.x < 0.0f, ngy = t.inv.y < 0.0f, ngz = t.inv.z < 0.0f;
+                    const uint32_t nwx = ngx ? q1.y : q1.x, fwx = ngx ? q1.x : q1.y;
+                    const uint32_t nwy = ngy ? q1.w : q1.z, fwy = ngy ? q1.z : q1.w;
+                    const uint32_t nwz = ngz ? q2.y : q2.x, fwz = ngz ? q2.x : q2.y;
+                    const uint32_t imask = (q2.z >> 24) & 15u;
+                    uint32_t hits = 0u, kmin = 0xffffffffu;
+                    float tns[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float qnx = (float)((nwx >> (8 * i)) & 0xffu), qfx = (float)((fwx >> (8 * i)) & 0xffu);
+                        const float qny = (float)((nwy >> (8 * i)) & 0xffu), qfy = (float)((fwy >> (8 * i)) & 0xffu);
+                        const float qnz = (float)((nwz >> (8 * i)) & 0xffu), qfz = (float)((fwz >> (8 * i)) & 0xffu);
+                        // fmaxf/fminf drop a NaN operand (0 * inf on an axis-parallel ray), which keeps the test conservative
+                        const float tn = fmaxf(fmaxf(__builtin_fmaf(qnx, stx, bnx), __builtin_fmaf(qny, sty, bny)),
+                                               fmaxf(__builtin_fmaf(qnz, stz, bnz), 0.0001f));
+                        float zf = __builtin_fmaf(qfz, stz, bfz);
+                        asm("v_min_f32 %0, %1, %2" : "=v"(zf) : "v"(zf), "v"(t.tbest)); // (tbest is +inf or a finite root: no canonicalising)
+                        const float tf = fminf(fminf(__builtin_fmaf(qfx, stx, bfx), __builtin_fmaf(qfy, sty, bfy)), zf);
+                        hits |= tn <= tf ? (1u << i) : 0u;
+                        tns[i] = tn;
+                    }
+                    hits &= q2.z >> 28; // children that exist
+                    if (STATS) st_node += (uint32_t)__popc(q2.z >> 28);
+                    const uint32_t lm = hits & ~imask, nm = hits & imask;
+                    // the nearest internal child that was hit goes first: entry distance (>= 1e-4, ordered like an integer) with
+                    // the child's number in its two low bits, all ones for children that are out
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t out = (uint32_t)(-(int32_t)((~nm >> i) & 1u));
+                        kmin = min(kmin, (__float_as_uint(tns[i]) & ~3u) | (uint32_t)i | out);
+                    }
+                    const uint32_t istar = kmin & 3u;
+                    // One stack entry per node: the internal children still to visit (mask in bits 24..27 on the node word's
+                    // base, bits 28..29 the one to take first).  Leaves that were hit are tested before anything else: they
+                    // become the lane's position and every internal child waits on the stack; without them the nearest child is
+                    // next and only the others are pushed.  Stored above the top unconditionally (one spare level).
+                    const uint32_t to_push = lm != 0u ? nm : (nm & ~(1u << istar));
+                    *stack_at(t.sp) = (StackS)((q2.z & 0x00ffffffu) | (to_push << 24) | (istar << 28));
+                    t.sp += to_push != 0u ? sp_stride : 0u;
+                    t.cur = lm != 0u ? (0x80000000u | (q2.w & 0x07ffffffu) | (lm << 27)) : (((q2.z & 0x00ffffffu) + istar) & 0x00ffffffu);
+                    pop = (lm | nm) == 0u;
+                } else if (!BIG && at_node) {
                     NodeFields nd;
-                    if (BIG) { // 48-byte records read through L1 / L2 / Infinity Cache (config 4)
-                        const uint4* np = lds_nodes + 3u * t.cur;
-                        const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
-                        nd = unpack_node48(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z);
-                    } else { // 64-byte records in LDS
+                    { // 64-byte records in LDS
                         const uint4* np = lds_nodes + 4u * t.cur;
                         const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                         nd = unpack_node64(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y);
@@ -575,8 +649,20 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? 8 : RTMI_WPE, BIG ? 8 :
                     pop = !(hit0 | hit1);
                 }
                 if (pop) {
-                    t.sp -= sp_stride;
-                    t.cur = (uint32_t)(int32_t)*stack_at(t.sp);
+                    if (BIG) {
+                        // the top entry hands out one internal child at a time: the preferred one while it is still there, then
+                        // the lowest; the entry leaves the stack with its last child (entry 0 of the stack is 0: the walk is over)
+                        const uint32_t e = (uint32_t)*stack_at(t.sp - sp_stride);
+                        const uint32_t mask = (e >> 24) & 15u, pref = (e >> 28) & 3u;
+                        const uint32_t i = ((mask >> pref) & 1u) != 0u ? pref : (uint32_t)__builtin_ctz(mask | 16u);
+                        const uint32_t rest = mask & ~(1u << i);
+                        t.cur = e == 0u ? kWalkDone4 : (((e & 0x00ffffffu) + i) & 0x00ffffffu);
+                        if (rest != 0u) *stack_at(t.sp - sp_stride) = (StackS)((e & 0x00ffffffu) | (rest << 24));
+                        t.sp -= (rest == 0u && e != 0u) ? sp_stride : 0u;
+                    } else {
+                        t.sp -= sp_stride;
+                        t.cur = (uint32_t)(int32_t)*stack_at(t.sp);
+                    }
                 }
             }
             if (phase == PH_TRAV && t.cur == kStackEnd) phase = PH_SHADE; // popped the sentinel: the walk is over
@@ -895,7 +981,7 @@ __global__ void __launch_bounds__(256) rtmi_resolve_kernel(const ResolveArgs A) 
 // chain slots are contiguous across the lanes: coalesced, where one lane per pixel would touch 64 B per sample in 64
 // different lines) and multiply their chains in parallel -- a chain is serial, the samples are not; the colours go to an
 // LDS tile and lanes 0 .. kResPix-1 add their pixel's 64 colours up in sample order (core.cc:260-263).  Albedos in LDS.
-constexpr uint32_t kResPix = 8, kResRow = 65; // (65: the summing lanes read one column, a power-of-two row stride would put them in one bank)
+constexpr uint32_t kResPix = 4, kResRow = 65; // (65: the summing lanes read one column, a power-of-two row stride would put them in one bank)
 __global__ void __launch_bounds__(256) rtmi_resolve_chain_kernel(const ResolveArgs A) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     uint4* lds_mats = reinterpret_cast<uint4*>(lds_raw);
@@ -917,23 +1003,32 @@ __global__ void __launch_bounds__(256) rtmi_resolve_chain_kernel(const ResolveAr
                     V3 color = mk(c.x, c.y, c.z);
                     const uint32_t n = __float_as_uint(c.w);
                     if (n != 0u) {
+                        // word by word from the last handle back to the first; within a word four handles at a time: their
+                        // albedo reads are in flight together (a chain is one LDS round trip per handle otherwise: the
+                        // multiplies depend on the read, the read on the handle)
                         const uint4* ch = reinterpret_cast<const uint4*>(A.chain_buf + rec * A.words);
-                        uint32_t wi = fdiv(n - 1u, A.div_epw), j = (n - 1u) - wi * A.epw; // position of the last handle
+                        uint32_t wi = fdiv(n - 1u, A.div_epw);
+                        uint32_t c = n - wi * A.epw; // handles in the last word
                         uint4 grp = ch[wi >> 2];
                         auto pick = [&](uint32_t w) { const uint32_t s_ = w & 3u; return s_ == 0u ? grp.x : (s_ == 1u ? grp.y : (s_ == 2u ? grp.z : grp.w)); };
-                        uint32_t word = pick(wi);
-                        for (uint32_t i = n; i != 0u; --i) {
-                            const uint4 m0 = lds_mats[(word >> (j * A.bits)) & mask];
-                            color = vmul(mk(__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z)), color);
-                            if (j == 0u) {
-                                if (i > 1u) {
-                                    if ((wi & 3u) == 0u) grp = ch[(wi - 1u) >> 2];
-                                    word = pick(--wi);
-                                }
-                                j = A.epw - 1u;
-                            } else {
-                                --j;
+                        auto albedo = [&](uint32_t h) { const uint4 m0 = lds_mats[h]; return mk(__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z)); };
+                        const uint32_t bits = A.bits;
+                        for (;;) {
+                            const uint32_t word = pick(wi);
+                            uint32_t sh = c * bits; // one past the top handle of this word
+                            for (; c >= 4u; c -= 4u, sh -= 4u * bits) {
+                                const V3 a0 = albedo((word >> (sh - bits)) & mask), a1 = albedo((word >> (sh - 2u * bits)) & mask);
+                                const V3 a2 = albedo((word >> (sh - 3u * bits)) & mask), a3 = albedo((word >> (sh - 4u * bits)) & mask);
+                                color = vmul(a0, color);
+                                color = vmul(a1, color);
+                                color = vmul(a2, color);
+                                color = vmul(a3, color);
                             }
+                            for (; c != 0u; --c, sh -= bits) color = vmul(albedo((word >> (sh - bits)) & mask), color);
+                            if (wi == 0u) break;
+                            if ((wi & 3u) == 0u) grp = ch[(wi - 1u) >> 2];
+                            --wi;
+                            c = A.epw;
                         }
                     }
                     tile[q * kResRow + lane] = make_float4(color.x, color.y, color.z, 0.0f);
@@ -1003,6 +1098,7 @@ struct rtmi_scene {
     bool big = false; // scene read from HBM instead of LDS
     uint32_t n_objects = 0, n_mats = 0;
     Bvh bvh;
+    Bvh4 bvh4; // HBM-resident scenes: the tree the kernel walks (bvh is the binary tree it was collapsed from)
     // device buffers
     uint4* d_spheres = nullptr;
     uint4* d_aux = nullptr;
@@ -1130,7 +1226,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.nodes = s->d_nodes;
     P.n_slots = s->n_objects;
     P.n_mats = s->n_mats;
-    P.n_nodes = (uint32_t)s->bvh.nodes.size();
+    P.n_nodes = (uint32_t)(s->big ? s->bvh4.nodes.size() : s->bvh.nodes.size());
     P.root_ref = s->root_ref_dev;
     std::memcpy(P.pre_leaf, s->pre_leaf_dev, sizeof(P.pre_leaf));
     P.n_pre_leaves = s->n_pre_leaves;
@@ -1433,16 +1529,36 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
 
     // slot order: leaf order for the BVH, insertion order for the linear scan
     std::vector<uint32_t> slot_object(n_objects);
+    if (tune.block_lanes) s->block = std::min(1024u, std::max(64u, (tune.block_lanes / 64u) * 64u));
     if (s->accel == RTMI_ACCEL_BVH) {
         build_bvh(objects, n_objects, opt.leaf_size ? opt.leaf_size : 2u, s->bvh);
         slot_object = s->bvh.slot_object;
-        if (n_objects >= 0x00ffffffu) {
-            set_error("rtmi_scene_create: too many objects (leaf references hold 24-bit slots)");
+        if (n_objects >= 0x007fffffu) {
+            set_error("rtmi_scene_create: too many objects (leaf references hold 23-bit slots)");
             return fail(RTMI_ERR_UNSUPPORTED);
         }
     } else {
         for (uint32_t i = 0; i < n_objects; ++i) slot_object[i] = i;
         s->bvh.root_ref = 0;
+    }
+    // Small scenes live in LDS entirely (two workgroups per CU must fit: 80 KiB each); larger ones stay in HBM, only the
+    // traversal stack is in LDS, and their tree is the 4-wide one with quantised boxes (rtmi_bvh4_node: three 16-byte
+    // reads for four boxes; its own slot order).
+    // (the same expression as the carve-up below, per-wave pools and alignment included: a scene within a kilobyte of the
+    // limit must not end up with one resident workgroup per CU instead of two)
+    s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) + 2u : 0u; // + the sentinel entry + one spare level (unconditional push store)
+    {
+        const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 16u;
+        const uint64_t small_total = ((scene_bytes + 15u) & ~15ull) + (((uint64_t)s->stack_depth * s->block * 2u + 15u) & ~15ull) +
+                                     (uint64_t)kAttLds * s->block * 4u + (uint64_t)(s->block / 64u) * 80u + 16u;
+        s->big = small_total > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u || n_objects > 0x2000u || n_materials > 0x10000u;
+        if (tune.force_hbm_scene) s->big = true;
+    }
+    if (s->big && s->accel == RTMI_ACCEL_BVH) {
+        if (opt.leaf_size > 2u) build_bvh(objects, n_objects, 2u, s->bvh); // a leaf of the 4-wide tree holds one or two spheres
+        build_bvh4(s->bvh, s->bvh4);
+        slot_object = s->bvh4.slot_object;
+        s->stack_depth = s->bvh4.depth + 2u;
     }
     std::vector<uint4> h_spheres(n_objects), h_aux(n_objects), h_mats((size_t)n_materials);
     auto fbits = [](float f) {
@@ -1471,18 +1587,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         }
     }
 
-    if (tune.block_lanes) s->block = std::min(1024u, std::max(64u, (tune.block_lanes / 64u) * 64u));
-    // LDS carve-up.  Small scenes live in LDS entirely (two workgroups per CU must fit: 80 KiB each); larger ones
-    // stay in HBM and only the traversal stack is in LDS.
     auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-    s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) + 2u : 0u; // + the sentinel entry + one spare level (unconditional push store)
-    // (the same expression as the carve-up below, per-wave pools and alignment included: a scene within a kilobyte of the
-    // limit must not end up with one resident workgroup per CU instead of two)
-    const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 16u;
-    const uint64_t small_total = ((scene_bytes + 15u) & ~15ull) + (((uint64_t)s->stack_depth * s->block * 2u + 15u) & ~15ull) +
-                                 (uint64_t)kAttLds * s->block * 4u + (uint64_t)(s->block / 64u) * 80u + 16u;
-    s->big = small_total > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u || n_objects > 0x2000u || n_materials > 0x10000u;
-    if (tune.force_hbm_scene) s->big = true;
     // HBM-resident scenes: the largest workgroup of which two fit the LDS with their stacks, up to 896 lanes (7 waves per
     // SIMD; 1024 would need 80 KB of stack at the depth of a 100k-sphere tree)
     if (s->big && !tune.block_lanes && s->accel == RTMI_ACCEL_BVH) {
@@ -1548,6 +1653,13 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
             return (ref & kLeafBit) ? (0xffff8000u | ((((ref >> 24) & 0x7fu) - 1u) << 13) | (ref & 0x1fffu)) : ref;
         };
         s->root_ref_dev = s->bvh.root_ref;
+        if (s->big && s->accel == RTMI_ACCEL_BVH) {
+            // the 4-wide tree: its builder has peeled the leaves at the top and encoded where the walk starts
+            s->root_ref_dev = s->bvh4.root;
+            s->n_pre_leaves = s->bvh4.n_pre_leaves;
+            std::memcpy(s->pre_leaf_dev, s->bvh4.pre_leaf, sizeof(s->pre_leaf_dev));
+            HIP_TRY_S(upload(&s->d_nodes, s->bvh4.nodes.data(), s->bvh4.nodes.size() * sizeof(rtmi_bvh4_node)));
+        }
         if (!s->big && s->accel == RTMI_ACCEL_BVH && n_objects > 0) {
             for (auto& nd : dn) {
                 nd.child[0] = pack16(nd.child[0]);
@@ -1557,66 +1669,25 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         }
         // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start
         // every walk below them
-        if (s->accel == RTMI_ACCEL_BVH && !dn.empty()) {
+        if (!s->big && s->accel == RTMI_ACCEL_BVH && !dn.empty()) {
             uint32_t cur = s->bvh.root_ref;
             while (!(cur & kLeafBit) && s->n_pre_leaves < 4u) {
                 const rtmi_bvh_node& nd = s->bvh.nodes[cur];
                 const bool l0 = (nd.child[0] & kLeafBit) != 0u, l1 = (nd.child[1] & kLeafBit) != 0u;
                 if (l0 && l1 && s->n_pre_leaves + 2u <= 4u) { // the spine ends in two leaves: nothing left to walk
-                    s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? nd.child[0] : pack16(nd.child[0]);
-                    s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? nd.child[1] : pack16(nd.child[1]);
+                    s->pre_leaf_dev[s->n_pre_leaves++] = pack16(nd.child[0]);
+                    s->pre_leaf_dev[s->n_pre_leaves++] = pack16(nd.child[1]);
                     cur = kNoWalk;
                     break;
                 }
                 if (l0 == l1) break;
                 const uint32_t leaf = l0 ? nd.child[0] : nd.child[1];
-                s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? leaf : pack16(leaf);
+                s->pre_leaf_dev[s->n_pre_leaves++] = pack16(leaf);
                 cur = l0 ? nd.child[1] : nd.child[0];
             }
-            if (s->n_pre_leaves) s->root_ref_dev = (cur == kNoWalk) ? kNoWalk : (s->big ? cur : pack16(cur));
+            if (s->n_pre_leaves) s->root_ref_dev = (cur == kNoWalk) ? kNoWalk : pack16(cur);
         }
-        if (s->big && !dn.empty()) {
-            // 48-byte records: centres fp32, half extents fp16 rounded up (an extent beyond fp16 becomes +inf: always hit),
-            // child references.  The exported tree (rtmi_scene_get_bvh) carries the rounded extents, so that an instrumented
-            // CPU walk tests the same boxes.
-            auto half_up = [](float v) -> uint16_t {
-                _Float16 h = (_Float16)v; // round to nearest
-                if ((float)h < v) {        // bump to the next fp16 above
-                    uint16_t bits;
-                    std::memcpy(&bits, &h, 2);
-                    bits = (uint16_t)(bits + 1u); // v > 0 here: the next representable value (or +inf)
-                    std::memcpy(&h, &bits, 2);
-                }
-                uint16_t out;
-                std::memcpy(&out, &h, 2);
-                return out;
-            };
-            auto half_to_float = [](uint16_t b) {
-                _Float16 h;
-                std::memcpy(&h, &b, 2);
-                return (float)h;
-            };
-            std::vector<uint32_t> rec(dn.size() * 12u, 0u);
-            for (size_t i = 0; i < dn.size(); ++i) {
-                uint32_t* r = &rec[i * 12u];
-                for (int k = 0; k < 2; ++k)
-                    for (int a = 0; a < 3; ++a) r[k * 3 + a] = fbits(dn[i].ctr[k][a]);
-                uint16_t hb[6];
-                for (int k = 0; k < 2; ++k)
-                    for (int a = 0; a < 3; ++a) {
-                        hb[k * 3 + a] = half_up(std::max(dn[i].half[k][a], 0.0f));
-                        s->bvh.nodes[i].half[k][a] = half_to_float(hb[k * 3 + a]);
-                    }
-                r[6] = hb[0] | ((uint32_t)hb[1] << 16);
-                r[7] = hb[2] | ((uint32_t)hb[3] << 16);
-                r[8] = hb[4] | ((uint32_t)hb[5] << 16);
-                r[9] = dn[i].child[0];
-                r[10] = dn[i].child[1];
-            }
-            HIP_TRY_S(upload(&s->d_nodes, rec.data(), rec.size() * sizeof(uint32_t)));
-        } else {
-            HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
-        }
+        if (!(s->big && s->accel == RTMI_ACCEL_BVH)) HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
     }
 
     // persistent grid: exactly as many workgroups as the device keeps resident
@@ -1666,6 +1737,10 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     }
 #else
     s->wf_enabled = s->accel == RTMI_ACCEL_BVH && n_objects > 0 && tune.kernel == 2u; // 0 / 1: round-based kernel
+    if (s->wf_enabled && s->big) {
+        set_error("rtmi_scene_create: the queue-scheduled kernel walks binary trees only (LDS-resident scenes)");
+        return fail(RTMI_ERR_UNSUPPORTED);
+    }
     if (s->wf_enabled) {
         if (tune.wf_block_lanes) s->wf_block = std::min(1024u, std::max(64u, (tune.wf_block_lanes / 64u) * 64u));
         if (tune.wf_refill) s->wf_refill = std::min(64u, tune.wf_refill);
@@ -1865,6 +1940,10 @@ extern "C" int rtmi_scene_get_bvh(const rtmi_scene* s, rtmi_bvh_node* nodes_out,
         set_error("rtmi_scene_get_bvh: scene has no BVH");
         return RTMI_ERR_UNSUPPORTED;
     }
+    if (s->big) {
+        set_error("rtmi_scene_get_bvh: the scene stays in HBM and is walked through the 4-wide tree (rtmi_scene_get_bvh4)");
+        return RTMI_ERR_UNSUPPORTED;
+    }
     if (n_nodes) *n_nodes = (uint32_t)s->bvh.nodes.size();
     if (n_slots) *n_slots = (uint32_t)s->bvh.slot_object.size();
     if (n_classes) *n_classes = s->bvh.n_pad_classes;
@@ -1872,6 +1951,31 @@ extern "C" int rtmi_scene_get_bvh(const rtmi_scene* s, rtmi_bvh_node* nodes_out,
     if (pad_floor) *pad_floor = s->bvh.pad_floor;
     if (nodes_out) std::memcpy(nodes_out, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(rtmi_bvh_node));
     if (slots_out) std::memcpy(slots_out, s->bvh.slot_object.data(), s->bvh.slot_object.size() * sizeof(uint32_t));
+    if (pad_classes_out) std::memcpy(pad_classes_out, s->bvh.pad_classes, s->bvh.n_pad_classes * 8 * sizeof(float));
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_get_bvh4(const rtmi_scene* s, rtmi_bvh4_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out,
+                                   uint32_t* n_slots, uint32_t* root_out, uint32_t pre_leaves_out[4], uint32_t* n_pre_leaves,
+                                   float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor) {
+    if (!s) {
+        set_error("rtmi_scene_get_bvh4: null scene");
+        return RTMI_ERR_BAD_ARG;
+    }
+    if (s->accel != RTMI_ACCEL_BVH || !s->big) {
+        set_error("rtmi_scene_get_bvh4: the scene is not walked through the 4-wide tree (LDS-resident, or no BVH)");
+        return RTMI_ERR_UNSUPPORTED;
+    }
+    if (n_nodes) *n_nodes = (uint32_t)s->bvh4.nodes.size();
+    if (n_slots) *n_slots = (uint32_t)s->bvh4.slot_object.size();
+    if (root_out) *root_out = s->bvh4.root;
+    if (n_pre_leaves) *n_pre_leaves = s->bvh4.n_pre_leaves;
+    if (pre_leaves_out) std::memcpy(pre_leaves_out, s->bvh4.pre_leaf, sizeof(s->bvh4.pre_leaf));
+    if (n_classes) *n_classes = s->bvh.n_pad_classes;
+    if (pad_eps) *pad_eps = s->bvh.pad_eps;
+    if (pad_floor) *pad_floor = s->bvh.pad_floor;
+    if (nodes_out) std::memcpy(nodes_out, s->bvh4.nodes.data(), s->bvh4.nodes.size() * sizeof(rtmi_bvh4_node));
+    if (slots_out) std::memcpy(slots_out, s->bvh4.slot_object.data(), s->bvh4.slot_object.size() * sizeof(uint32_t));
     if (pad_classes_out) std::memcpy(pad_classes_out, s->bvh.pad_classes, s->bvh.n_pad_classes * 8 * sizeof(float));
     return RTMI_OK;
 }
