@@ -13,8 +13,12 @@ import numpy as np
 import rtmi_loader
 pkg = rtmi_loader.load()
 here = os.path.dirname(pkg.LIB_PATH)
-prof_lib = os.path.join(here, "librtmi_prof.so")      # -DRTMI_PROF=1: cycle stamps + walk lanes
-census_lib = os.path.join(here, "librtmi_census.so")  # -DRTMI_PROF=2: branch census
+prefix = "librtmi_prof"
+for a in sys.argv[1:]:
+    if a.startswith("--libs="):  # another pair of diagnostic libraries (an older build for an A/B): <prefix>1.so, <prefix>2.so
+        prefix = a.split("=", 1)[1]
+prof_lib = os.path.join(here, prefix + "1.so")    # -DRTMI_PROF=1: cycle stamps + walk lanes
+census_lib = os.path.join(here, prefix + "2.so")  # -DRTMI_PROF=2: branch census
 static_json = os.path.join(here, "librtmi_prof_static.json")
 
 
