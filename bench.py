@@ -436,8 +436,9 @@ def main(argv=None):
             frame_h = frame.cpu().numpy()
             xs, ys = rng.integers(0, W, n_chk), rng.integers(0, H, n_chk)
             obvh = None
-            if len(objs) > 4096:  # the oracle's own linear scan over 100k spheres takes minutes per pixel: walk the tree
-                obvh = pkg.bvh4_build(objs)
+            if len(objs) > 4096:  # the oracle's own linear scan over 100k spheres takes minutes per pixel: walk the BVH
+                obvh = pkg.bvh_build(objs)
+                obvh = dict(obvh, nodes=obvh["nodes"].view(ob.BVH_NODE_DTYPE))
             worst = 0.0
             for x, y in zip(xs, ys):
                 want, _ = ob.render_rect_counter(ocam, objs, mats, RENDER_SEED, int(x), int(y), int(x) + 1, int(y) + 1,
@@ -447,13 +448,9 @@ def main(argv=None):
                 worst = max(worst, float(d.max()))
             out["parity_check"] = {"pixels": n_chk, "max_abs_diff_vs_oracle": worst,
                                    "oracle": "linear scan" if obvh is None else "instrumented BVH walk (== linear scan, tests)"}
-        # the tree the kernel walks: binary for LDS-resident scenes, the 4-wide one with quantised boxes for HBM-resident ones
-        bvh = None
-        if args.accel == "bvh":
-            in_lds = scene.launch_info()["scene_in_lds"] if scene is not None else len(objs) <= 600
-            bvh = pkg.bvh_build(objs) if in_lds else pkg.bvh4_build(objs)
-            if in_lds:
-                bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
+        bvh = pkg.bvh_build(objs) if args.accel == "bvh" else None
+        if bvh is not None:
+            bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
         ctr_stride = 24
         ctr = {"samples": 0, "segments": 0, "sphere_tests": 0, "node_tests": 0, "hit_lambertian": 0, "hit_metallic": 0}
         sub_spp = min(spp, 64)
@@ -504,7 +501,7 @@ def main(argv=None):
             # pass reads them back) + framebuffer slice; the path is VALU-bound, HBM is reported as a sanity check
             # + in packed-chain launches the material handles a path leaves for the resolve pass (its non-dielectric bounces x
             # ceil(log2 n_materials) bits; the slot the launch reserves per sample is chain_words x 4 bytes)
-            "hbm_algorithmic_bytes_per_launch": int(len(objs) * (16 + 16 + 32) + (0 if bvh is None else len(bvh["nodes"]) * bvh["nodes"].dtype.itemsize)
+            "hbm_algorithmic_bytes_per_launch": int(len(objs) * (16 + 16 + 32) + (0 if bvh is None else len(bvh["nodes"]) * 64)
                                                     + samples_per_launch * (16 + chain_bytes) + W * (H // n_gpus) * 16),
             "chain_words_per_sample": chain_words,
             "note": "fp32 VALU-bound path (SURVEY 8d): peak = non-FMA issue rate 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",

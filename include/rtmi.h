@@ -108,7 +108,7 @@ typedef struct rtmi_tuning {
     uint32_t block_lanes;       /* lanes per workgroup, multiple of 64 (default 768: 2 x 768 per CU = 6 waves per SIMD) */
     uint32_t blocks_per_cu;     /* cap on resident workgroups per CU (default: the occupancy query) */
     uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 52) */
-    uint32_t reserved0;         /* (was drain_wait_thresh: the deferred-path queue of rounds 1-2 is gone) must be 0 */
+    uint32_t reserved0;         /* (was drain_wait_thresh: the deferred-path queue of rounds 1-2 is gone) ignored */
     int32_t chunk_samples;      /* samples per work item: 0 = auto, -1 = whole pixels (no sample records), n > 0 = n */
     int32_t chain_mode;         /* attenuation chains: 0 = auto (packed strings of material handles in LDS, multiplied by the
                                  * resolve pass, when they fit next to the scene; else run-length encoded runs with per-lane
@@ -147,22 +147,6 @@ typedef struct rtmi_bvh_node {
     uint32_t child[2]; /* bit31 set: leaf {bits 0..23 first slot, bits 24..30 count}; else node index */
     float reserved[2];
 } rtmi_bvh_node;
-
-/* 4-wide node of scenes that stay in HBM (more than ~640 spheres): 48 B = three 16-byte reads.  The boxes of the (up to
- * four) children are 8-bit offsets on the node's own origin, one power-of-two quantum per axis, rounded outwards -- boxes
- * only have to be supersets ("Exactness of the BVH").  Leaf children come first; a leaf holds one or two
- * spheres in consecutive slots, the leaves of a node follow each other in the slot order, its internal children follow
- * each other in the node array.  plane of child i on axis a: org[a] + q * 2^(e_a - 127), q = byte i of lo_a / hi_a. */
-typedef struct rtmi_bvh4_node {
-    float org[3];
-    uint32_t exps;    /* bits 0..7, 8..15, 16..23: biased exponents e_x, e_y, e_z of the quanta */
-    uint32_t lo_x, hi_x, lo_y, hi_y, lo_z, hi_z; /* byte i: child i */
-    uint32_t nodes;   /* bits 0..23: (index of the first internal child - number of leaf children) mod 2^24, so that internal
-                       * child i is node (nodes + i) mod 2^24; bits 24..27: mask of internal children; 28..31: mask of
-                       * children that exist */
-    uint32_t leaves;  /* bits 0..22: slot of the first sphere of the first leaf child; bits 23..26: bit i set = leaf child i
-                       * holds two spheres */
-} rtmi_bvh4_node;
 
 typedef struct rtmi_scene rtmi_scene; /* opaque: owns the device copies of camera, objects, materials, BVH */
 
@@ -238,23 +222,11 @@ int rtmi_scene_get_launch_info(const rtmi_scene* scene, rtmi_launch_info* out);
 int rtmi_scene_get_bvh(const rtmi_scene* scene, rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out,
                        uint32_t* n_slots, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,
                        float* pad_floor);
-/* The 4-wide tree of an HBM-resident scene (rtmi_launch_info::scene_in_lds == 0), as rtmi_bvh4_build returns it; for
- * LDS-resident scenes RTMI_ERR_UNSUPPORTED (and rtmi_scene_get_bvh likewise for HBM-resident ones). */
-int rtmi_scene_get_bvh4(const rtmi_scene* scene, rtmi_bvh4_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out,
-                        uint32_t* n_slots, uint32_t* root_out, uint32_t pre_leaves_out[4], uint32_t* n_pre_leaves,
-                        float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor);
 /* Host-only BVH build (no device needed): the structure rtmi_scene_create would build for these objects.
  * nodes_out / slots_out need room for n_objects records, pad_classes_out for 32 floats; any output may be NULL. */
 int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, rtmi_bvh_node* nodes_out,
                    uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref, uint32_t* depth,
                    float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor);
-/* The 4-wide tree of HBM-resident scenes, host-only build (what rtmi_scene_create builds for such a scene).  root_out: the
- * reference the walk starts at below the peeled leaves -- a node index, 0x80000000 | leaf word for a single leaf, or
- * 0xffffffff when the peeled leaves are the whole tree; pre_leaves_out: up to four leaves (bits 0..23 first slot, bits
- * 24..30 count) tested at segment set-up.  nodes_out / slots_out need room for n_objects records; outputs may be NULL. */
-int rtmi_bvh4_build(const rtmi_object* objects, uint32_t n_objects, rtmi_bvh4_node* nodes_out, uint32_t* n_nodes,
-                    uint32_t* slots_out, uint32_t* root_out, uint32_t* depth, uint32_t pre_leaves_out[4],
-                    uint32_t* n_pre_leaves, float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor);
 /* duration in milliseconds of the most recent TRACE kernel of this scene (the ordered resolve pass that follows it is
  * not included), from HIP events recorded on the launch stream; blocks until that launch has finished.  Used by
  * bench.py for the roofline line. */

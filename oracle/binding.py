@@ -108,11 +108,6 @@ def lib():
                                               C.c_uint32, vp, C.c_uint32, C.c_float, C.c_float, C.c_uint64,
                                               C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp,
                                               C.POINTER(Counters), C.c_int]
-    L.orc_render_rect_counter_bvh4.restype = C.c_int
-    L.orc_render_rect_counter_bvh4.argtypes = [C.POINTER(Camera), vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp,
-                                               C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_float,
-                                               C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp,
-                                               vp, C.POINTER(Counters), C.c_int]
     L.orc_bench_mt.restype = C.c_double
     L.orc_bench_mt.argtypes = [C.POINTER(Camera), vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp,
                                C.POINTER(C.c_uint64)]
@@ -211,8 +206,7 @@ def render_pixels_mt(cam, objs, mats, mt_seed, xy, counters=False):
 
 
 def render_rect_counter(cam, objs, mats, seed, x0, y0, x1, y1, nthreads=1, counters=False, bvh=None):
-    """bvh = dict(nodes, slots, pad_classes, pad_eps, pad_floor) switches to the instrumented BVH walk (binary tree: 64-byte
-    nodes; with root and pre_leaves and 48-byte nodes: the product's 4-wide tree of HBM-resident scenes)."""
+    """bvh = dict(nodes, slots, pad_classes, pad_eps, pad_floor) switches to the instrumented BVH walk."""
     w, h = x1 - x0, y1 - y0
     rgb = np.zeros((h, w, 3), np.float32)
     rgba = np.zeros((h, w), np.uint32)
@@ -225,15 +219,6 @@ def render_rect_counter(cam, objs, mats, seed, x0, y0, x1, y1, nthreads=1, count
         nodes = np.ascontiguousarray(bvh["nodes"])
         slots = np.ascontiguousarray(bvh["slots"], dtype=np.uint32)
         pc = np.ascontiguousarray(bvh["pad_classes"], dtype=np.float32).reshape(-1, 8)
-        if "root" in bvh:
-            assert len(nodes) == 0 or nodes.dtype.itemsize == 48
-            pre = np.ascontiguousarray(bvh["pre_leaves"], dtype=np.uint32)
-            rc = lib().orc_render_rect_counter_bvh4(C.byref(cam), _ptr(objs), len(objs), _ptr(mats), len(mats), _ptr(nodes),
-                                                    len(nodes), _ptr(slots), len(slots), int(bvh["root"]), _ptr(pre), len(pre),
-                                                    _ptr(pc), len(pc), bvh["pad_eps"], bvh["pad_floor"], seed, x0, y0, x1, y1,
-                                                    _ptr(rgb), _ptr(rgba), cp, nthreads)
-            assert rc == 0, rc
-            return (rgb, rgba, ctr.as_dict()) if counters else (rgb, rgba)
         assert nodes.dtype.itemsize == 64
         rc = lib().orc_render_rect_counter_bvh(C.byref(cam), _ptr(objs), len(objs), _ptr(mats), len(mats),
                                                _ptr(nodes), len(nodes), _ptr(slots), len(slots), _ptr(pc), len(pc),

@@ -472,11 +472,6 @@ typedef struct {
     const float* pad_classes;
     uint32_t n_classes;
     float pad_eps, pad_floor;
-    /* optional 4-wide tree of the product's HBM-resident scenes (instrumented walk) */
-    const orc_bvh4_node* nodes4;
-    uint32_t root4;
-    uint32_t pre4[4];
-    uint32_t n_pre4;
 } scene_t;
 
 /* HittableObject_Collection::intersects, object.defs.cc:68-81: linear scan in insertion order,
@@ -545,120 +540,8 @@ static inline float ray_pad(const scene_t* sc, const ray_t* r) {
     return e;
 }
 
-static int finish_hit(const scene_t* sc, const ray_t* r, uint32_t best, float best_t, hit_rec* rec, uint32_t* index);
-
-/* The walk of the product's 4-wide tree (raytracing.cpp_amd/csrc/rtmi_device.hip, BIG variant), restated for the work
- * counters: same boxes (planes org + q * 2^e evaluated in ray parameters with the same FMAs, pad in the near / far
- * offsets), same order (hit leaves first, then the nearest internal child, the others in storage order from one stack
- * entry per node).  The closest hit does not depend on the order or on which superset boxes are used (DESIGN.md,
- * "Exactness of the BVH"): it is the linear scan's. */
-static int bvh4_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec* rec, uint32_t* index,
-                           orc_counters* ctr) {
-    const float inv[3] = {1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z};
-    const float o[3] = {r->o.x, r->o.y, r->o.z};
-    const float pad = ray_pad(sc, r);
-    float oinv[3], pinv[3];
-    for (int i = 0; i < 3; ++i) {
-        oinv[i] = -(o[i] * inv[i]);
-        pinv[i] = pad * fabsf(inv[i]);
-    }
-    float best_t = INFINITY;
-    uint32_t best = 0xffffffffu;
-#define ORC_TEST_SLOTS(first_, count_)                                                                       \
-    for (uint32_t s_ = 0; s_ < (count_); ++s_) {                                                             \
-        const uint32_t oi = sc->slots[(first_) + s_];                                                        \
-        const float cand = sphere_candidate(&sc->objs[oi], r, tmin);                                         \
-        if (ctr) ctr->sphere_tests++;                                                                        \
-        if (cand > tmin && (cand < best_t || (cand == best_t && oi < best))) {                               \
-            best_t = cand;                                                                                   \
-            best = oi;                                                                                       \
-        }                                                                                                    \
-    }
-    for (uint32_t q = 0; q < sc->n_pre4; ++q) ORC_TEST_SLOTS(sc->pre4[q] & 0x00ffffffu, (sc->pre4[q] >> 24) & 0x7fu)
-    uint32_t stack[64];
-    int sp = 0;
-    uint32_t cur = sc->root4;
-    const uint32_t done = 0x00ffffffu;
-    if (cur == 0xffffffffu) cur = done; /* the peeled leaves were the whole tree */
-    while (cur != done) {
-        int pop = 0;
-        if (cur & 0x80000000u) { /* a leaf group: one leaf at a time, lowest first */
-            const uint32_t lm = (cur >> 27) & 15u, two = (cur >> 23) & 15u;
-            uint32_t i = 0;
-            while (!((lm >> i) & 1u)) ++i;
-            uint32_t before = 0;
-            for (uint32_t j = 0; j < i; ++j) before += (two >> j) & 1u;
-            ORC_TEST_SLOTS((cur & 0x007fffffu) + i + before, 1u + ((two >> i) & 1u))
-            const uint32_t rest = lm & (lm - 1u);
-            cur = (cur & ~(15u << 27)) | (rest << 27);
-            pop = rest == 0u;
-        } else {
-            const orc_bvh4_node* nd = &sc->nodes4[cur];
-            const uint32_t valid = nd->nodes >> 28, imask = (nd->nodes >> 24) & 15u;
-            uint32_t hits = 0;
-            float tns[4];
-            for (int i = 0; i < 4; ++i) {
-                float tn = tmin, tf = best_t;
-                for (int a = 0; a < 3; ++a) {
-                    uint32_t eb = ((nd->exps >> (8 * a)) & 0xffu) << 23;
-                    float sc_;
-                    memcpy(&sc_, &eb, 4);
-                    const float st = sc_ * inv[a];
-                    const float b = fmaf(nd->org[a], inv[a], oinv[a]);
-                    const int neg = inv[a] < 0.0f;
-                    const float qn = (float)((nd->q[2 * a + (neg ? 1 : 0)] >> (8 * i)) & 0xffu);
-                    const float qf = (float)((nd->q[2 * a + (neg ? 0 : 1)] >> (8 * i)) & 0xffu);
-                    tn = fmaxf(tn, fmaf(qn, st, b - pinv[a])); /* fmaxf / fminf drop a NaN operand, as v_max / v_min do */
-                    tf = fminf(tf, fmaf(qf, st, b + pinv[a]));
-                }
-                tns[i] = tn;
-                if (tn <= tf) hits |= 1u << i;
-            }
-            hits &= valid;
-            if (ctr) {
-                for (uint32_t j = 0; j < 4; ++j) ctr->node_tests += (valid >> j) & 1u;
-            }
-            const uint32_t lm = hits & ~imask, nm = hits & imask;
-            uint32_t kmin = 0xffffffffu;
-            for (uint32_t i = 0; i < 4; ++i) {
-                if (!((nm >> i) & 1u)) continue;
-                uint32_t kb;
-                memcpy(&kb, &tns[i], 4);
-                kb = (kb & ~3u) | i;
-                if (kb < kmin) kmin = kb;
-            }
-            const uint32_t istar = kmin & 3u;
-            const uint32_t to_push = lm ? nm : (nm & ~(1u << istar));
-            if (to_push) stack[sp++] = (nd->nodes & 0x00ffffffu) | (to_push << 24) | (istar << 28);
-            if (lm) cur = 0x80000000u | (nd->leaves & 0x07ffffffu) | (lm << 27);
-            else if (nm) cur = ((nd->nodes & 0x00ffffffu) + istar) & 0x00ffffffu;
-            else pop = 1;
-        }
-        if (pop) {
-            if (sp == 0) {
-                cur = done;
-            } else {
-                const uint32_t e = stack[sp - 1];
-                const uint32_t mask = (e >> 24) & 15u, pref = (e >> 28) & 3u;
-                uint32_t i = pref;
-                if (!((mask >> pref) & 1u)) {
-                    i = 0;
-                    while (!((mask >> i) & 1u)) ++i;
-                }
-                const uint32_t rest = mask & ~(1u << i);
-                cur = ((e & 0x00ffffffu) + i) & 0x00ffffffu;
-                if (rest) stack[sp - 1] = (e & 0x00ffffffu) | (rest << 24);
-                else --sp;
-            }
-        }
-    }
-#undef ORC_TEST_SLOTS
-    return finish_hit(sc, r, best, best_t, rec, index);
-}
-
 static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec* rec, uint32_t* index,
                           orc_counters* ctr) {
-    if (sc->nodes4 || sc->n_pre4) return bvh4_intersects(sc, r, tmin, rec, index, ctr);
     const float inv[3] = {1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z};
     const float o[3] = {r->o.x, r->o.y, r->o.z};
     const float pad = ray_pad(sc, r);
@@ -753,10 +636,6 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
             cur = stack[--sp];
         }
     }
-    return finish_hit(sc, r, best, best_t, rec, index);
-}
-
-static int finish_hit(const scene_t* sc, const ray_t* r, uint32_t best, float best_t, hit_rec* rec, uint32_t* index) {
     if (best == 0xffffffffu) {
         return 0;
     }
@@ -1055,23 +934,6 @@ int orc_render_rect_counter(const orc_camera* cam, const orc_object* objs, uint3
     scene_t sc;
     memset(&sc, 0, sizeof(sc));
     sc.objs = objs; sc.n_objs = n_objs; sc.mats = mats; sc.n_mats = n_mats;
-    return render_rect(cam, &sc, seed, x0, y0, x1, y1, rgb_out, rgba_out, ctr, nthreads);
-}
-
-int orc_render_rect_counter_bvh4(const orc_camera* cam, const orc_object* objs, uint32_t n_objs,
-                                 const orc_material* mats, uint32_t n_mats, const orc_bvh4_node* nodes, uint32_t n_nodes,
-                                 const uint32_t* slots, uint32_t n_slots, uint32_t root, const uint32_t* pre_leaves,
-                                 uint32_t n_pre_leaves, const float* pad_classes, uint32_t n_classes, float pad_eps,
-                                 float pad_floor, uint64_t seed, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
-                                 float* rgb_out, uint32_t* rgba_out, orc_counters* ctr, int nthreads) {
-    scene_t sc;
-    memset(&sc, 0, sizeof(sc));
-    sc.objs = objs; sc.n_objs = n_objs; sc.mats = mats; sc.n_mats = n_mats;
-    sc.nodes4 = nodes; sc.n_nodes = n_nodes; sc.slots = slots; sc.n_slots = n_slots; sc.root4 = root;
-    if (n_pre_leaves > 4u || n_slots == 0 || (n_nodes == 0 && n_pre_leaves == 0 && !(root & 0x80000000u))) return -1;
-    for (uint32_t i = 0; i < n_pre_leaves; ++i) sc.pre4[i] = pre_leaves[i];
-    sc.n_pre4 = n_pre_leaves;
-    sc.pad_classes = pad_classes; sc.n_classes = n_classes; sc.pad_eps = pad_eps; sc.pad_floor = pad_floor;
     return render_rect(cam, &sc, seed, x0, y0, x1, y1, rgb_out, rgba_out, ctr, nthreads);
 }
 

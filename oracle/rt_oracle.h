@@ -98,15 +98,6 @@ typedef struct orc_bvh_node {
     float inv2rmin[2];
 } orc_bvh_node;
 
-/* the product's 4-wide node of HBM-resident scenes (rtmi_bvh4_node, include/rtmi.h): child boxes as 8-bit offsets on
- * the node's origin, one power-of-two quantum per axis; leaves first, one or two spheres each */
-typedef struct orc_bvh4_node {
-    float org[3];
-    uint32_t exps;
-    uint32_t q[6]; /* lo_x, hi_x, lo_y, hi_y, lo_z, hi_z: byte i = child i */
-    uint32_t nodes, leaves;
-} orc_bvh4_node;
-
 enum { ORC_RNG_MT19937 = 0, ORC_RNG_COUNTER = 1 };
 
 /* --- RNG ---------------------------------------------------------------- */
@@ -169,15 +160,6 @@ int orc_render_rect_counter_bvh(const orc_camera* cam, const orc_object* objs, u
                                 const uint32_t* slots, uint32_t n_slots, const float* pad_classes, uint32_t n_classes,
                                 float pad_eps, float pad_floor, uint64_t seed, uint32_t x0, uint32_t y0, uint32_t x1,
                                 uint32_t y1, float* rgb_out, uint32_t* rgba_out, orc_counters* ctr, int nthreads);
-
-/* The same through the product's 4-wide tree (instrumented walk: node_tests counts the child boxes of every visited
- * node).  root: where the walk starts below the peeled leaves (rtmi_bvh4_build). */
-int orc_render_rect_counter_bvh4(const orc_camera* cam, const orc_object* objs, uint32_t n_objs,
-                                 const orc_material* mats, uint32_t n_mats, const orc_bvh4_node* nodes, uint32_t n_nodes,
-                                 const uint32_t* slots, uint32_t n_slots, uint32_t root, const uint32_t* pre_leaves,
-                                 uint32_t n_pre_leaves, const float* pad_classes, uint32_t n_classes, float pad_eps,
-                                 float pad_floor, uint64_t seed, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
-                                 float* rgb_out, uint32_t* rgba_out, orc_counters* ctr, int nthreads);
 
 /* CPU baseline: the reference's job system shape (src/main.cc:608-633): nthreads workers, shuffled 8x8 tiles from
  * a shared queue, one mt19937 per worker; renders every `stride`-th pixel in x and y. Returns wall seconds. */

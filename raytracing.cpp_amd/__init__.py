@@ -135,15 +135,13 @@ from . import workloads  # noqa: E402  (scene + camera generators of the BASELIN
 OBJECT_DTYPE, MATERIAL_DTYPE = workloads.OBJECT_DTYPE, workloads.MATERIAL_DTYPE
 BVH_NODE_DTYPE = np.dtype([("ctr", "<f4", (2, 3)), ("half", "<f4", (2, 3)), ("child", "<u4", 2),
                            ("reserved", "<f4", 2)])
-BVH4_NODE_DTYPE = np.dtype([("org", "<f4", 3), ("exps", "<u4"), ("q", "<u4", 6), ("nodes", "<u4"), ("leaves", "<u4")])
 assert OBJECT_DTYPE.itemsize == 24 and MATERIAL_DTYPE.itemsize == 20 and BVH_NODE_DTYPE.itemsize == 64
-assert BVH4_NODE_DTYPE.itemsize == 48
 
 # every symbol include/rtmi.h declares
 EXPORTS = ("rtmi_camera_setup", "rtmi_make_world_spheres", "rtmi_scene_create", "rtmi_scene_destroy",
            "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_last_error", "rtmi_version",
            "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_launch_info", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
-           "rtmi_bvh_build", "rtmi_bvh4_build", "rtmi_scene_get_bvh4", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
+           "rtmi_bvh_build", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
            "rtmi_frame_render_device", "rtmi_frame_get_timing", "rtmi_frame_rccl_ranks", "rtmi_frame_get_scene")
 
 _lib = None
@@ -185,8 +183,6 @@ def lib():
     L.rtmi_scene_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     u32p, f32p = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
     L.rtmi_bvh_build.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u32p, vp, u32p, u32p, vp, u32p, f32p, f32p]
-    L.rtmi_bvh4_build.argtypes = [vp, C.c_uint32, vp, u32p, vp, u32p, u32p, vp, u32p, vp, u32p, f32p, f32p]
-    L.rtmi_scene_get_bvh4.argtypes = [vp, vp, u32p, vp, u32p, u32p, vp, u32p, vp, u32p, f32p, f32p]
     L.rtmi_frame_create.argtypes = [C.POINTER(Camera), vp, C.c_uint32, vp, C.c_uint32, C.POINTER(SceneOptions),
                                     C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.rtmi_frame_destroy.argtypes = [vp]
@@ -341,21 +337,6 @@ class Scene:
         _check(lib().rtmi_scene_last_kernel_ms(self._h, C.byref(v)))
         return v.value
 
-    def bvh4(self):
-        """rtmi_scene_get_bvh4: the 4-wide tree of an HBM-resident scene (the dict oracle.binding.render_rect_counter takes)."""
-        nn, ns, nc, root, npre = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
-        eps, floor = C.c_float(0), C.c_float(0)
-        _check(lib().rtmi_scene_get_bvh4(self._h, None, C.byref(nn), None, C.byref(ns), C.byref(root), None, C.byref(npre),
-                                         None, C.byref(nc), C.byref(eps), C.byref(floor)))
-        nodes = np.zeros(nn.value, BVH4_NODE_DTYPE)
-        slots = np.zeros(ns.value, np.uint32)
-        pre = np.zeros(4, np.uint32)
-        pc = np.zeros((nc.value, 8), np.float32)
-        _check(lib().rtmi_scene_get_bvh4(self._h, _ptr(nodes), None, _ptr(slots), None, None, _ptr(pre), None, _ptr(pc), None,
-                                         None, None))
-        return dict(nodes=nodes, slots=slots, root=root.value, pre_leaves=pre[:npre.value].copy(), pad_classes=pc,
-                    pad_eps=eps.value, pad_floor=floor.value)
-
     def bvh(self):
         nn, ns, nc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         eps, floor = C.c_float(0), C.c_float(0)
@@ -437,23 +418,6 @@ def bvh_build(objs, leaf_size=0):
                                 C.byref(depth), _ptr(pc), C.byref(nc), C.byref(eps), C.byref(floor)))
     return dict(nodes=nodes[:nn.value].copy(), slots=slots[:n].copy(), pad_classes=pc[:nc.value].copy(),
                 pad_eps=eps.value, pad_floor=floor.value, root_ref=root.value, depth=depth.value)
-
-
-def bvh4_build(objs):
-    """rtmi_bvh4_build: the 4-wide tree HBM-resident scenes are walked through (host-only, no device needed)."""
-    objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
-    n = len(objs)
-    nodes = np.zeros(max(n, 1), BVH4_NODE_DTYPE)
-    slots = np.zeros(max(n, 1), np.uint32)
-    pre = np.zeros(4, np.uint32)
-    pc = np.zeros((4, 8), np.float32)
-    nn, root, depth, npre, nc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
-    eps, floor = C.c_float(0), C.c_float(0)
-    _check(lib().rtmi_bvh4_build(_ptr(objs), n, _ptr(nodes), C.byref(nn), _ptr(slots), C.byref(root), C.byref(depth),
-                                 _ptr(pre), C.byref(npre), _ptr(pc), C.byref(nc), C.byref(eps), C.byref(floor)))
-    return dict(nodes=nodes[:nn.value].copy(), slots=slots[:n].copy(), root=root.value, depth=depth.value,
-                pre_leaves=pre[:npre.value].copy(), pad_classes=pc[:nc.value].copy(), pad_eps=eps.value,
-                pad_floor=floor.value)
 
 
 def row_block_shards(height, block_rows, world_size):

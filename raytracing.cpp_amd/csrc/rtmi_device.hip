@@ -52,7 +52,8 @@ constexpr uint32_t kBlackSample = 0xfffffffeu; // Trav::best of a sample that is
 #endif
 
 #ifndef RTMI_WPE_BIG
-#define RTMI_WPE_BIG 7 // HBM-resident scenes: two 896-lane workgroups per CU = 7 waves per SIMD = 72 VGPRs
+#define RTMI_WPE_BIG 6 // HBM-resident scenes: 8 = 64 VGPRs, the compiler's walk, two 896-lane workgroups per CU (round 2);
+                       // 6 = the hand-written node loop (v66-v79 are its node registers), two 768-lane workgroups
 #endif
 
 #ifndef RTMI_ASM_WALK
@@ -160,6 +161,97 @@ DEV void walk_nodes_lds(Trav& t, uint32_t nbase, uint32_t stride, int floor, int
           "v78", "v79");
 }
 
+// The same loop for trees that stay in HBM (config 4: 100k spheres): 48-byte nodes -- both centres fp32, the six half extents
+// fp16 (rounded up on the host), two child references -- read with three 16-byte loads through L1 / L2 / Infinity Cache,
+// 32-bit stack entries.  v_fma_mix_f32 takes the fp16 half extents as they are (exact conversion inside the FMA: the same
+// value as v_cvt_f32_f16 + v_fma_f32, six instructions less per trip).
+//   v66-v69 = c0x c0y c0z c1x   v70-v73 = c1y c1z h0x|h0y h0z|h1x   v74-v77 = h1y|h1z ch0 ch1 -
+DEV void walk_nodes_hbm(Trav& t, const uint4* nodes, uint32_t stride, int floor, int& n_leaf, int& n_node) {
+    int tmp;
+    uint64_t m_node, m_leaf, saved, hit0, hit1;
+    float x, y, z, tn0;
+    asm volatile(
+        "L_top_%=:\n\t"
+        "v_cmp_le_i32_e64 %[mnode], 0, %[cur]\n\t"
+        "v_cmp_gt_i32_e64 %[mleaf], -1, %[cur]\n\t"
+        "s_bcnt1_i32_b64 %[nnode], %[mnode]\n\t"
+        "s_bcnt1_i32_b64 %[nleaf], %[mleaf]\n\t"
+        "s_add_i32 %[tmp], %[nnode], %[nleaf]\n\t"
+        "s_cmp_le_i32 %[tmp], %[floor]\n\t"
+        "s_cbranch_scc1 L_exit_%=\n\t"
+        "s_cmp_gt_i32 %[nleaf], %[nnode]\n\t"
+        "s_cbranch_scc1 L_exit_%=\n\t"
+        "s_and_saveexec_b64 %[saved], %[mnode]\n\t"
+        "v_mul_u32_u24_e32 %[x], 48, %[cur]\n\t"
+        "global_load_dwordx4 v[66:69], %[x], %[nodes]\n\t"
+        "global_load_dwordx4 v[70:73], %[x], %[nodes] offset:16\n\t"
+        "global_load_dwordx4 v[74:77], %[x], %[nodes] offset:32\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_fma_f32 v66, v66, %[ix], %[ox]\n\t"      // tc0x
+        "v_fma_f32 v67, v67, %[iy], %[oy]\n\t"      // tc0y
+        "v_fma_f32 v68, v68, %[iz], %[oz]\n\t"      // tc0z
+        "v_fma_f32 v69, v69, %[ix], %[ox]\n\t"      // tc1x
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_fma_f32 v70, v70, %[iy], %[oy]\n\t"      // tc1y
+        "v_fma_f32 v71, v71, %[iz], %[oz]\n\t"      // tc1z
+        "v_fma_mix_f32 v78, v72, |%[ix]|, %[px] op_sel_hi:[1,0,0]\n\t"                  // th0x: the pad rides in the FMA of the half extent
+        "v_fma_mix_f32 v72, v72, |%[iy]|, %[py] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th0y
+        "v_fma_mix_f32 v79, v73, |%[iz]|, %[pz] op_sel_hi:[1,0,0]\n\t"                  // th0z
+        "v_fma_mix_f32 v73, v73, |%[ix]|, %[px] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th1x
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_fma_mix_f32 v77, v74, |%[iy]|, %[py] op_sel_hi:[1,0,0]\n\t"                  // th1y
+        "v_fma_mix_f32 v74, v74, |%[iz]|, %[pz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th1z
+        "v_sub_f32_e32 %[x], v66, v78\n\t"          // box 0, near: max(x, y, max(z, 1e-4))
+        "v_sub_f32_e32 %[y], v67, v72\n\t"
+        "v_sub_f32_e32 %[z], v68, v79\n\t"
+        "v_max_f32_e32 %[z], 0x38d1b717, %[z]\n\t"
+        "v_max3_f32 %[tn0], %[x], %[y], %[z]\n\t"
+        "v_add_f32_e32 %[x], v66, v78\n\t"          // far: min(x, y, min(z, tbest))
+        "v_add_f32_e32 %[y], v67, v72\n\t"
+        "v_add_f32_e32 %[z], v68, v79\n\t"
+        "v_min_f32_e32 %[z], %[z], %[tbest]\n\t"
+        "v_min3_f32 %[x], %[x], %[y], %[z]\n\t"
+        "v_cmp_le_f32_e64 %[hit0], %[tn0], %[x]\n\t"
+        "v_sub_f32_e32 %[x], v69, v73\n\t"          // box 1
+        "v_sub_f32_e32 %[y], v70, v77\n\t"
+        "v_sub_f32_e32 %[z], v71, v74\n\t"
+        "v_max_f32_e32 %[z], 0x38d1b717, %[z]\n\t"
+        "v_max3_f32 v66, %[x], %[y], %[z]\n\t"      // tn1
+        "v_add_f32_e32 %[x], v69, v73\n\t"
+        "v_add_f32_e32 %[y], v70, v77\n\t"
+        "v_add_f32_e32 %[z], v71, v74\n\t"
+        "v_min_f32_e32 %[z], %[z], %[tbest]\n\t"
+        "v_min3_f32 %[x], %[x], %[y], %[z]\n\t"
+        "v_cmp_le_f32_e64 %[hit1], v66, %[x]\n\t"
+        "v_cmp_lt_f32_e32 vcc, v66, %[tn0]\n\t"     // nearer1
+        "s_orn2_b64 vcc, vcc, %[hit0]\n\t"
+        "s_and_b64 %[mleaf], %[hit1], vcc\n\t"      // take1 = hit1 & (!hit0 | nearer1): the nearer child first
+        "v_cndmask_b32_e64 %[x], v76, v75, %[mleaf]\n\t"   // the far child: take1 ? ch0 : ch1
+        "ds_write_b32 %[sp], %[x]\n\t"
+        "v_cndmask_b32_e64 %[cur], v75, v76, %[mleaf]\n\t" // take1 ? ch1 : ch0
+        "s_and_b64 vcc, %[hit0], %[hit1]\n\t"
+        "v_cndmask_b32_e32 %[y], 0, %[stride], vcc\n\t"
+        "v_add_u32_e32 %[sp], %[sp], %[y]\n\t"
+        "s_or_b64 vcc, %[hit0], %[hit1]\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"           // neither box hit: pop
+        "s_cbranch_execz L_nopop_%=\n\t"
+        "v_sub_u32_e32 %[sp], %[sp], %[stride]\n\t"
+        "ds_read_b32 %[cur], %[sp]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "L_nopop_%=:\n\t"
+        "s_mov_b64 exec, %[saved]\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_exit_%=:"
+        : [cur] "+v"(t.cur), [sp] "+v"(t.sp), [nleaf] "=&s"(n_leaf), [nnode] "=&s"(n_node), [tmp] "=&s"(tmp),
+          [mnode] "=&s"(m_node), [mleaf] "=&s"(m_leaf), [saved] "=&s"(saved), [hit0] "=&s"(hit0), [hit1] "=&s"(hit1),
+          [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [tn0] "=&v"(tn0)
+        : [ix] "v"(t.inv.x), [iy] "v"(t.inv.y), [iz] "v"(t.inv.z), [ox] "v"(t.oinv.x), [oy] "v"(t.oinv.y),
+          [oz] "v"(t.oinv.z), [px] "v"(t.pinv.x), [py] "v"(t.pinv.y), [pz] "v"(t.pinv.z), [tbest] "v"(t.tbest),
+          [stride] "v"(stride), [nodes] "s"(nodes), [floor] "s"(floor)
+        : "vcc", "scc", "memory", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
+          "v78", "v79");
+}
+
 // BIG = false: the whole scene is staged into LDS and stack entries are packed into 16 bits (<= 8192 spheres).
 // BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
 //              32-bit entries (config 4: 100k spheres, 2.4 MB of spheres + 6.4 MB of nodes).
@@ -182,13 +274,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
     // signed: nodes >= 0, leaves < -1, the sentinel -1 (16-bit entries are read back sign-extended); t.sp is an LDS address
     using StackS = typename std::conditional<BIG, int32_t, int16_t>::type;
     typedef __attribute__((address_space(3))) StackS lds_stack_t;
-    // "not walking": the 16-bit walk keeps the popped sentinel (-1) there, the 4-wide walk of HBM-resident scenes its own
-    // reference encoding (rtmi_internal.h: node index < 2^24 - 1 | 0x80000000 + leaf group | kWalkDone4; stack sentinel 0)
-    constexpr uint32_t kStackEnd = BIG ? kWalkDone4 : 0xffffffffu;
+    constexpr uint32_t kStackEnd = 0xffffffffu;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8*)lds_raw;
     const uint32_t sp0 = lds0 + P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT), sp_stride = blockDim.x * (uint32_t)sizeof(StackT);
     auto stack_at = [](uint32_t addr) -> lds_stack_t* { return (lds_stack_t*)(uintptr_t)addr; };
-    if (ACCEL == RTMI_ACCEL_BVH) *stack_at(sp0) = BIG ? (StackS)0 : (StackS)-1;
+    if (ACCEL == RTMI_ACCEL_BVH) *stack_at(sp0) = (StackS)-1;
     uint32_t* lds_att = reinterpret_cast<uint32_t*>(lds_raw + P.lds_att);
     // per-wave pools: work indices are taken from the global counter 64 at a time (a single counter word saturates at
     // ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M work items)
@@ -306,7 +396,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
     };
     // the spheres of one leaf against the current segment, two at a time: both discriminants, then the (rare) roots.
     // The first pair is straight code -- with the default leaf size of 2 it is the whole leaf -- larger leaves loop on
-    auto test_slots = [&](uint32_t first, uint32_t cnt) {
+    auto test_leaf = [&](uint32_t ref) {
+        const uint32_t first = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
+        const uint32_t cnt = BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u);
         t.a = vdot(t.d, t.d); // (recomputed here: not a register across the node steps)
         const Recip ra = recip_for(t.a); // shared by every root of this leaf step
         auto pair = [&](uint32_t q) {
@@ -324,9 +416,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             for (uint32_t q = 2u; q < cnt; q += 2u) pair(q);
         }
         if (STATS) st_sphere += cnt;
-    };
-    auto test_leaf = [&](uint32_t ref) { // a leaf reference: 24-bit slot + count (HBM-resident scenes), 13-bit slot + count - 1 (LDS)
-        test_slots(BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu), BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u));
     };
     auto begin_segment = [&](V3 o, V3 d) {
         t.o = o;
@@ -430,6 +519,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
         // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
         ISA_MARK("gen");
         PB(1, phase == PH_GEN);
+        // (a gate on this branch -- run it only when K lanes need a primary ray or one has waited T rounds -- was measured
+        // on configs 3, 4 and 5: +-0 at best, slower from K = 8 up; profiles/r03_gating_experiment.txt)
         if (phase == PH_GEN) {
             const uint32_t gy = fdiv(rng.pixel, P.div_w), px = rng.pixel - gy * W; // (rng.pixel = gy * W + px came with the work item)
             rng.k = 0;
@@ -502,9 +593,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             const int trav_floor = max(0, (int)__popcll(ballot(phase == PH_TRAV || phase == PH_SHADE)) - (int)P.wait_thresh);
             for (;;) {
 #if RTMI_ASM_WALK && !(defined(RTMI_PROF) && RTMI_PROF == 1)
-                if (!BIG && !STATS) {
+                if (!STATS && (!BIG || RTMI_WPE_BIG <= 6)) {
                     int n_leaf, n_node;
-                    walk_nodes_lds(t, lds0, sp_stride, trav_floor, n_leaf, n_node); // nodes start the dynamic LDS segment
+                    if (BIG) walk_nodes_hbm(t, lds_nodes, sp_stride, trav_floor, n_leaf, n_node);
+                    else walk_nodes_lds(t, lds0, sp_stride, trav_floor, n_leaf, n_node); // nodes start the dynamic LDS segment
                     if (n_leaf + n_node <= trav_floor) break;
                     if ((int32_t)t.cur < -1) { // the leaf step won the vote
                         test_leaf(t.cur);
@@ -514,10 +606,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                     continue;
                 }
 #endif
-                // (16-bit walk: nodes >= 0, leaves < -1, inline constants; 4-wide walk: a leaf group has bit 31 set, a node index
-                // is below kWalkDone4)
-                const bool at_leaf = BIG ? (int32_t)t.cur < 0 : (int32_t)t.cur < -1;
-                const bool at_node = BIG ? t.cur < kWalkDone4 : (int32_t)t.cur >= 0;
+                const bool at_leaf = (int32_t)t.cur < -1, at_node = (int32_t)t.cur >= 0; // (inline constants)
                 const uint64_t m_leaf = ballot(at_leaf);
                 const uint64_t m_node = ballot(at_node);
 #if defined(RTMI_PROF) && RTMI_PROF == 1
@@ -534,81 +623,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                 if (n_leaf > n_node) {
                     PF_MARK(3);
                     if (at_leaf) {
-                        if (BIG) {
-                            // a leaf group: bits 0..22 first slot, 23..26 "two spheres" per leaf child, 27..30 the leaves still
-                            // to test (their boxes were hit); one leaf per trip, lowest first
-                            const uint32_t lm = (t.cur >> 27) & 15u, two = (t.cur >> 23) & 15u;
-                            const uint32_t i = (uint32_t)__builtin_ctz(lm);
-                            test_slots((t.cur & 0x007fffffu) + i + (uint32_t)__popc(two & ((1u << i) - 1u)), 1u + ((two >> i) & 1u));
-                            const uint32_t rest = lm & (lm - 1u);
-                            t.cur = (t.cur & ~(15u << 27)) | (rest << 27);
-                            pop = rest == 0u;
-                        } else {
-                            test_leaf(t.cur);
-                            pop = true;
-                        }
+                        test_leaf(t.cur);
+                        pop = true;
                     }
                     PF_MARK(21);
-                } else if (BIG && at_node) {
-                    // ---- 4-wide node, 48 bytes through L1 / L2 / Infinity Cache: three 16-byte reads for four boxes ----
-                    const uint4* np = lds_nodes + 3u * t.cur;
-                    const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
-                    // plane q of an axis sits at org + q * 2^e; in ray parameters t(q) = q * (2^e / d) + (org - o) / d, and the pad
-                    // (pinv = pad * |1/d|) moves near planes down, far planes up
-                    const float stx = __uint_as_float((q0.w & 0xffu) << 23) * t.inv.x;
-                    const float sty = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * t.inv.y;
-                    const float stz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * t.inv.z;
-                    const float bx = __builtin_fmaf(__uint_as_float(q0.x), t.inv.x, t.oinv.x);
-                    const float by = __builtin_fmaf(__uint_as_float(q0.y), t.inv.y, t.oinv.y);
-                    const float bz = __builtin_fmaf(__uint_as_float(q0.z), t.inv.z, t.oinv.z);
-                    const float bnx = bx - t.pinv.x, bfx = bx + t.pinv.x;
-                    const float bny = by - t.pinv.y, bfy = by + t.pinv.y;
-                    const float bnz = bz - t.pinv.z, bfz = bz + t.pinv.z;
-                    // a ray that runs down an axis enters through the high plane
-                    const bool ngx = t.inv.x < 0.0f, ngy = t.inv.y < 0.0f, ngz = t.inv.z < 0.0f;
-                    const uint32_t nwx = ngx ? q1.y : q1.x, fwx = ngx ? q1.x : q1.y;
-                    const uint32_t nwy = ngy ? q1.w : q1.z, fwy = ngy ? q1.z : q1.w;
-                    const uint32_t nwz = ngz ? q2.y : q2.x, fwz = ngz ? q2.x : q2.y;
-                    const uint32_t imask = (q2.z >> 24) & 15u;
-                    uint32_t hits = 0u, kmin = 0xffffffffu;
-                    float tns[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float qnx = (float)((nwx >> (8 * i)) & 0xffu), qfx = (float)((fwx >> (8 * i)) & 0xffu);
-                        const float qny = (float)((nwy >> (8 * i)) & 0xffu), qfy = (float)((fwy >> (8 * i)) & 0xffu);
-                        const float qnz = (float)((nwz >> (8 * i)) & 0xffu), qfz = (float)((fwz >> (8 * i)) & 0xffu);
-                        // fmaxf/fminf drop a NaN operand (0 * inf on an axis-parallel ray), which keeps the test conservative
-                        const float tn = fmaxf(fmaxf(__builtin_fmaf(qnx, stx, bnx), __builtin_fmaf(qny, sty, bny)),
-                                               fmaxf(__builtin_fmaf(qnz, stz, bnz), 0.0001f));
-                        float zf = __builtin_fmaf(qfz, stz, bfz);
-                        asm("v_min_f32 %0, %1, %2" : "=v"(zf) : "v"(zf), "v"(t.tbest)); // (tbest is +inf or a finite root: no canonicalising)
-                        const float tf = fminf(fminf(__builtin_fmaf(qfx, stx, bfx), __builtin_fmaf(qfy, sty, bfy)), zf);
-                        hits |= tn <= tf ? (1u << i) : 0u;
-                        tns[i] = tn;
-                    }
-                    hits &= q2.z >> 28; // children that exist
-                    if (STATS) st_node += (uint32_t)__popc(q2.z >> 28);
-                    const uint32_t lm = hits & ~imask, nm = hits & imask;
-                    // the nearest internal child that was hit goes first: entry distance (>= 1e-4, ordered like an integer) with
-                    // the child's number in its two low bits, all ones for children that are out
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t out = (uint32_t)(-(int32_t)((~nm >> i) & 1u));
-                        kmin = min(kmin, (__float_as_uint(tns[i]) & ~3u) | (uint32_t)i | out);
-                    }
-                    const uint32_t istar = kmin & 3u;
-                    // One stack entry per node: the internal children still to visit (mask in bits 24..27 on the node word's
-                    // base, bits 28..29 the one to take first).  Leaves that were hit are tested before anything else: they
-                    // become the lane's position and every internal child waits on the stack; without them the nearest child is
-                    // next and only the others are pushed.  Stored above the top unconditionally (one spare level).
-                    const uint32_t to_push = lm != 0u ? nm : (nm & ~(1u << istar));
-                    *stack_at(t.sp) = (StackS)((q2.z & 0x00ffffffu) | (to_push << 24) | (istar << 28));
-                    t.sp += to_push != 0u ? sp_stride : 0u;
-                    t.cur = lm != 0u ? (0x80000000u | (q2.w & 0x07ffffffu) | (lm << 27)) : (((q2.z & 0x00ffffffu) + istar) & 0x00ffffffu);
-                    pop = (lm | nm) == 0u;
-                } else if (!BIG && at_node) {
+                } else if (at_node) {
                     NodeFields nd;
-                    { // 64-byte records in LDS
+                    if (BIG) { // 48-byte records read through L1 / L2 / Infinity Cache (config 4)
+                        const uint4* np = lds_nodes + 3u * t.cur;
+                        const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
+                        nd = unpack_node48(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z);
+                    } else { // 64-byte records in LDS
                         const uint4* np = lds_nodes + 4u * t.cur;
                         const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                         nd = unpack_node64(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y);
@@ -649,20 +674,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                     pop = !(hit0 | hit1);
                 }
                 if (pop) {
-                    if (BIG) {
-                        // the top entry hands out one internal child at a time: the preferred one while it is still there, then
-                        // the lowest; the entry leaves the stack with its last child (entry 0 of the stack is 0: the walk is over)
-                        const uint32_t e = (uint32_t)*stack_at(t.sp - sp_stride);
-                        const uint32_t mask = (e >> 24) & 15u, pref = (e >> 28) & 3u;
-                        const uint32_t i = ((mask >> pref) & 1u) != 0u ? pref : (uint32_t)__builtin_ctz(mask | 16u);
-                        const uint32_t rest = mask & ~(1u << i);
-                        t.cur = e == 0u ? kWalkDone4 : (((e & 0x00ffffffu) + i) & 0x00ffffffu);
-                        if (rest != 0u) *stack_at(t.sp - sp_stride) = (StackS)((e & 0x00ffffffu) | (rest << 24));
-                        t.sp -= (rest == 0u && e != 0u) ? sp_stride : 0u;
-                    } else {
-                        t.sp -= sp_stride;
-                        t.cur = (uint32_t)(int32_t)*stack_at(t.sp);
-                    }
+                    t.sp -= sp_stride;
+                    t.cur = (uint32_t)(int32_t)*stack_at(t.sp);
                 }
             }
             if (phase == PH_TRAV && t.cur == kStackEnd) phase = PH_SHADE; // popped the sentinel: the walk is over
@@ -1098,7 +1111,6 @@ struct rtmi_scene {
     bool big = false; // scene read from HBM instead of LDS
     uint32_t n_objects = 0, n_mats = 0;
     Bvh bvh;
-    Bvh4 bvh4; // HBM-resident scenes: the tree the kernel walks (bvh is the binary tree it was collapsed from)
     // device buffers
     uint4* d_spheres = nullptr;
     uint4* d_aux = nullptr;
@@ -1131,6 +1143,7 @@ struct rtmi_scene {
     // lanes waiting for shading that end a traversal round (A/B on MI355X, round 2: 52 = 56 on the LDS-resident RTOW
     // scene, 3.5 % better than 56 on the HBM-resident 100k-sphere scene; 62 costs that scene 23 %)
     uint32_t wait_thresh = 52;
+
     uint32_t lds_att = 0, lds_pool = 0;
     uint32_t n_cus = 0;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
@@ -1226,7 +1239,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.nodes = s->d_nodes;
     P.n_slots = s->n_objects;
     P.n_mats = s->n_mats;
-    P.n_nodes = (uint32_t)(s->big ? s->bvh4.nodes.size() : s->bvh.nodes.size());
+    P.n_nodes = (uint32_t)s->bvh.nodes.size();
     P.root_ref = s->root_ref_dev;
     std::memcpy(P.pre_leaf, s->pre_leaf_dev, sizeof(P.pre_leaf));
     P.n_pre_leaves = s->n_pre_leaves;
@@ -1321,6 +1334,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.div_block_rows = make_fastdiv(P.block_rows);
     P.div_w = make_fastdiv(W);
     P.wait_thresh = s->wait_thresh;
+
     P.seed = mix_seed(seed); // two key words, see rng4x32
     P.out_rgb = d_rgb;
     P.out_rgba = d_rgba;
@@ -1529,36 +1543,16 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
 
     // slot order: leaf order for the BVH, insertion order for the linear scan
     std::vector<uint32_t> slot_object(n_objects);
-    if (tune.block_lanes) s->block = std::min(1024u, std::max(64u, (tune.block_lanes / 64u) * 64u));
     if (s->accel == RTMI_ACCEL_BVH) {
         build_bvh(objects, n_objects, opt.leaf_size ? opt.leaf_size : 2u, s->bvh);
         slot_object = s->bvh.slot_object;
-        if (n_objects >= 0x007fffffu) {
-            set_error("rtmi_scene_create: too many objects (leaf references hold 23-bit slots)");
+        if (n_objects >= 0x00ffffffu) {
+            set_error("rtmi_scene_create: too many objects (leaf references hold 24-bit slots)");
             return fail(RTMI_ERR_UNSUPPORTED);
         }
     } else {
         for (uint32_t i = 0; i < n_objects; ++i) slot_object[i] = i;
         s->bvh.root_ref = 0;
-    }
-    // Small scenes live in LDS entirely (two workgroups per CU must fit: 80 KiB each); larger ones stay in HBM, only the
-    // traversal stack is in LDS, and their tree is the 4-wide one with quantised boxes (rtmi_bvh4_node: three 16-byte
-    // reads for four boxes; its own slot order).
-    // (the same expression as the carve-up below, per-wave pools and alignment included: a scene within a kilobyte of the
-    // limit must not end up with one resident workgroup per CU instead of two)
-    s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) + 2u : 0u; // + the sentinel entry + one spare level (unconditional push store)
-    {
-        const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 16u;
-        const uint64_t small_total = ((scene_bytes + 15u) & ~15ull) + (((uint64_t)s->stack_depth * s->block * 2u + 15u) & ~15ull) +
-                                     (uint64_t)kAttLds * s->block * 4u + (uint64_t)(s->block / 64u) * 80u + 16u;
-        s->big = small_total > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u || n_objects > 0x2000u || n_materials > 0x10000u;
-        if (tune.force_hbm_scene) s->big = true;
-    }
-    if (s->big && s->accel == RTMI_ACCEL_BVH) {
-        if (opt.leaf_size > 2u) build_bvh(objects, n_objects, 2u, s->bvh); // a leaf of the 4-wide tree holds one or two spheres
-        build_bvh4(s->bvh, s->bvh4);
-        slot_object = s->bvh4.slot_object;
-        s->stack_depth = s->bvh4.depth + 2u;
     }
     std::vector<uint4> h_spheres(n_objects), h_aux(n_objects), h_mats((size_t)n_materials);
     auto fbits = [](float f) {
@@ -1587,10 +1581,21 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         }
     }
 
+    if (tune.block_lanes) s->block = std::min(1024u, std::max(64u, (tune.block_lanes / 64u) * 64u));
+    // LDS carve-up.  Small scenes live in LDS entirely (two workgroups per CU must fit: 80 KiB each); larger ones
+    // stay in HBM and only the traversal stack is in LDS.
     auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+    s->stack_depth = s->accel == RTMI_ACCEL_BVH ? std::max(1u, s->bvh.depth) + 2u : 0u; // + the sentinel entry + one spare level (unconditional push store)
+    // (the same expression as the carve-up below, per-wave pools and alignment included: a scene within a kilobyte of the
+    // limit must not end up with one resident workgroup per CU instead of two)
+    const uint64_t scene_bytes = (uint64_t)s->bvh.nodes.size() * 64u + (uint64_t)n_objects * 32u + (uint64_t)n_materials * 16u;
+    const uint64_t small_total = ((scene_bytes + 15u) & ~15ull) + (((uint64_t)s->stack_depth * s->block * 2u + 15u) & ~15ull) +
+                                 (uint64_t)kAttLds * s->block * 4u + (uint64_t)(s->block / 64u) * 80u + 16u;
+    s->big = small_total > 80u * 1024u || s->bvh.nodes.size() >= 0x8000u || n_objects > 0x2000u || n_materials > 0x10000u;
+    if (tune.force_hbm_scene) s->big = true;
     // HBM-resident scenes: the largest workgroup of which two fit the LDS with their stacks, up to 896 lanes (7 waves per
     // SIMD; 1024 would need 80 KB of stack at the depth of a 100k-sphere tree)
-    if (s->big && !tune.block_lanes && s->accel == RTMI_ACCEL_BVH) {
+    if (RTMI_WPE_BIG > 6 && s->big && !tune.block_lanes && s->accel == RTMI_ACCEL_BVH) {
         s->block = 896u;
         while (s->block > 768u && (uint64_t)s->stack_depth * s->block * 4u + (s->block / 64u) * 80u + 64u > 80u * 1024u) s->block -= 64u;
     }
@@ -1653,13 +1658,6 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
             return (ref & kLeafBit) ? (0xffff8000u | ((((ref >> 24) & 0x7fu) - 1u) << 13) | (ref & 0x1fffu)) : ref;
         };
         s->root_ref_dev = s->bvh.root_ref;
-        if (s->big && s->accel == RTMI_ACCEL_BVH) {
-            // the 4-wide tree: its builder has peeled the leaves at the top and encoded where the walk starts
-            s->root_ref_dev = s->bvh4.root;
-            s->n_pre_leaves = s->bvh4.n_pre_leaves;
-            std::memcpy(s->pre_leaf_dev, s->bvh4.pre_leaf, sizeof(s->pre_leaf_dev));
-            HIP_TRY_S(upload(&s->d_nodes, s->bvh4.nodes.data(), s->bvh4.nodes.size() * sizeof(rtmi_bvh4_node)));
-        }
         if (!s->big && s->accel == RTMI_ACCEL_BVH && n_objects > 0) {
             for (auto& nd : dn) {
                 nd.child[0] = pack16(nd.child[0]);
@@ -1669,25 +1667,66 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         }
         // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start
         // every walk below them
-        if (!s->big && s->accel == RTMI_ACCEL_BVH && !dn.empty()) {
+        if (s->accel == RTMI_ACCEL_BVH && !dn.empty()) {
             uint32_t cur = s->bvh.root_ref;
             while (!(cur & kLeafBit) && s->n_pre_leaves < 4u) {
                 const rtmi_bvh_node& nd = s->bvh.nodes[cur];
                 const bool l0 = (nd.child[0] & kLeafBit) != 0u, l1 = (nd.child[1] & kLeafBit) != 0u;
                 if (l0 && l1 && s->n_pre_leaves + 2u <= 4u) { // the spine ends in two leaves: nothing left to walk
-                    s->pre_leaf_dev[s->n_pre_leaves++] = pack16(nd.child[0]);
-                    s->pre_leaf_dev[s->n_pre_leaves++] = pack16(nd.child[1]);
+                    s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? nd.child[0] : pack16(nd.child[0]);
+                    s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? nd.child[1] : pack16(nd.child[1]);
                     cur = kNoWalk;
                     break;
                 }
                 if (l0 == l1) break;
                 const uint32_t leaf = l0 ? nd.child[0] : nd.child[1];
-                s->pre_leaf_dev[s->n_pre_leaves++] = pack16(leaf);
+                s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? leaf : pack16(leaf);
                 cur = l0 ? nd.child[1] : nd.child[0];
             }
-            if (s->n_pre_leaves) s->root_ref_dev = (cur == kNoWalk) ? kNoWalk : pack16(cur);
+            if (s->n_pre_leaves) s->root_ref_dev = (cur == kNoWalk) ? kNoWalk : (s->big ? cur : pack16(cur));
         }
-        if (!(s->big && s->accel == RTMI_ACCEL_BVH)) HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
+        if (s->big && !dn.empty()) {
+            // 48-byte records: centres fp32, half extents fp16 rounded up (an extent beyond fp16 becomes +inf: always hit),
+            // child references.  The exported tree (rtmi_scene_get_bvh) carries the rounded extents, so that an instrumented
+            // CPU walk tests the same boxes.
+            auto half_up = [](float v) -> uint16_t {
+                _Float16 h = (_Float16)v; // round to nearest
+                if ((float)h < v) {        // bump to the next fp16 above
+                    uint16_t bits;
+                    std::memcpy(&bits, &h, 2);
+                    bits = (uint16_t)(bits + 1u); // v > 0 here: the next representable value (or +inf)
+                    std::memcpy(&h, &bits, 2);
+                }
+                uint16_t out;
+                std::memcpy(&out, &h, 2);
+                return out;
+            };
+            auto half_to_float = [](uint16_t b) {
+                _Float16 h;
+                std::memcpy(&h, &b, 2);
+                return (float)h;
+            };
+            std::vector<uint32_t> rec(dn.size() * 12u, 0u);
+            for (size_t i = 0; i < dn.size(); ++i) {
+                uint32_t* r = &rec[i * 12u];
+                for (int k = 0; k < 2; ++k)
+                    for (int a = 0; a < 3; ++a) r[k * 3 + a] = fbits(dn[i].ctr[k][a]);
+                uint16_t hb[6];
+                for (int k = 0; k < 2; ++k)
+                    for (int a = 0; a < 3; ++a) {
+                        hb[k * 3 + a] = half_up(std::max(dn[i].half[k][a], 0.0f));
+                        s->bvh.nodes[i].half[k][a] = half_to_float(hb[k * 3 + a]);
+                    }
+                r[6] = hb[0] | ((uint32_t)hb[1] << 16);
+                r[7] = hb[2] | ((uint32_t)hb[3] << 16);
+                r[8] = hb[4] | ((uint32_t)hb[5] << 16);
+                r[9] = dn[i].child[0];
+                r[10] = dn[i].child[1];
+            }
+            HIP_TRY_S(upload(&s->d_nodes, rec.data(), rec.size() * sizeof(uint32_t)));
+        } else {
+            HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
+        }
     }
 
     // persistent grid: exactly as many workgroups as the device keeps resident
@@ -1710,6 +1749,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     HIP_TRY_S(hipGetDeviceProperties(&prop, dev));
     if (tune.blocks_per_cu) per_cu = std::max(1, std::min(per_cu, (int)tune.blocks_per_cu));
     if (tune.wait_thresh) s->wait_thresh = std::min(64u, tune.wait_thresh);
+
     if (tune.chunk_samples) s->chunk = tune.chunk_samples < 0 ? 0u : (uint32_t)tune.chunk_samples; // 0: split off
     if (tune.sample_buf_mb) s->sample_buf_cap_bytes = (size_t)tune.sample_buf_mb << 20;
     s->top_down = tune.top_down != 0;
@@ -1737,10 +1777,6 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     }
 #else
     s->wf_enabled = s->accel == RTMI_ACCEL_BVH && n_objects > 0 && tune.kernel == 2u; // 0 / 1: round-based kernel
-    if (s->wf_enabled && s->big) {
-        set_error("rtmi_scene_create: the queue-scheduled kernel walks binary trees only (LDS-resident scenes)");
-        return fail(RTMI_ERR_UNSUPPORTED);
-    }
     if (s->wf_enabled) {
         if (tune.wf_block_lanes) s->wf_block = std::min(1024u, std::max(64u, (tune.wf_block_lanes / 64u) * 64u));
         if (tune.wf_refill) s->wf_refill = std::min(64u, tune.wf_refill);
@@ -1940,10 +1976,6 @@ extern "C" int rtmi_scene_get_bvh(const rtmi_scene* s, rtmi_bvh_node* nodes_out,
         set_error("rtmi_scene_get_bvh: scene has no BVH");
         return RTMI_ERR_UNSUPPORTED;
     }
-    if (s->big) {
-        set_error("rtmi_scene_get_bvh: the scene stays in HBM and is walked through the 4-wide tree (rtmi_scene_get_bvh4)");
-        return RTMI_ERR_UNSUPPORTED;
-    }
     if (n_nodes) *n_nodes = (uint32_t)s->bvh.nodes.size();
     if (n_slots) *n_slots = (uint32_t)s->bvh.slot_object.size();
     if (n_classes) *n_classes = s->bvh.n_pad_classes;
@@ -1951,31 +1983,6 @@ extern "C" int rtmi_scene_get_bvh(const rtmi_scene* s, rtmi_bvh_node* nodes_out,
     if (pad_floor) *pad_floor = s->bvh.pad_floor;
     if (nodes_out) std::memcpy(nodes_out, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(rtmi_bvh_node));
     if (slots_out) std::memcpy(slots_out, s->bvh.slot_object.data(), s->bvh.slot_object.size() * sizeof(uint32_t));
-    if (pad_classes_out) std::memcpy(pad_classes_out, s->bvh.pad_classes, s->bvh.n_pad_classes * 8 * sizeof(float));
-    return RTMI_OK;
-}
-
-extern "C" int rtmi_scene_get_bvh4(const rtmi_scene* s, rtmi_bvh4_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out,
-                                   uint32_t* n_slots, uint32_t* root_out, uint32_t pre_leaves_out[4], uint32_t* n_pre_leaves,
-                                   float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor) {
-    if (!s) {
-        set_error("rtmi_scene_get_bvh4: null scene");
-        return RTMI_ERR_BAD_ARG;
-    }
-    if (s->accel != RTMI_ACCEL_BVH || !s->big) {
-        set_error("rtmi_scene_get_bvh4: the scene is not walked through the 4-wide tree (LDS-resident, or no BVH)");
-        return RTMI_ERR_UNSUPPORTED;
-    }
-    if (n_nodes) *n_nodes = (uint32_t)s->bvh4.nodes.size();
-    if (n_slots) *n_slots = (uint32_t)s->bvh4.slot_object.size();
-    if (root_out) *root_out = s->bvh4.root;
-    if (n_pre_leaves) *n_pre_leaves = s->bvh4.n_pre_leaves;
-    if (pre_leaves_out) std::memcpy(pre_leaves_out, s->bvh4.pre_leaf, sizeof(s->bvh4.pre_leaf));
-    if (n_classes) *n_classes = s->bvh.n_pad_classes;
-    if (pad_eps) *pad_eps = s->bvh.pad_eps;
-    if (pad_floor) *pad_floor = s->bvh.pad_floor;
-    if (nodes_out) std::memcpy(nodes_out, s->bvh4.nodes.data(), s->bvh4.nodes.size() * sizeof(rtmi_bvh4_node));
-    if (slots_out) std::memcpy(slots_out, s->bvh4.slot_object.data(), s->bvh4.slot_object.size() * sizeof(uint32_t));
     if (pad_classes_out) std::memcpy(pad_classes_out, s->bvh.pad_classes, s->bvh.n_pad_classes * 8 * sizeof(float));
     return RTMI_OK;
 }

@@ -9,7 +9,6 @@
 #include <limits>
 #include <new>
 #include <random>
-#include <stdexcept>
 
 #include "rtmi_internal.h"
 
@@ -563,221 +562,7 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
     }
 }
 
-// ---- the 4-wide tree of HBM-resident scenes ---------------------------------------------------------------------------
-// Collapsed from the binary SAH tree: a node takes the two children of a binary node and keeps replacing the internal
-// child of largest surface area by that child's own two children until it has four (or only leaves are left).  Leaves
-// first, internal children after them; internal children of a node get consecutive indices, the spheres of its leaf
-// children consecutive slots.  Child boxes are stored as 8-bit offsets on the node's origin in units of a per-axis power of
-// two, rounded outwards (checked in extended precision): the walk only needs supersets of the binary tree's boxes.
-void build_bvh4(const Bvh& bin, Bvh4& out) {
-    out = Bvh4{};
-    const uint32_t n = static_cast<uint32_t>(bin.slot_object.size());
-    out.slot_object.reserve(n);
-    auto take_leaf = [&](uint32_t leaf, uint32_t& first_out, uint32_t& cnt_out) {
-        const uint32_t first = leaf & 0x00ffffffu, cnt = (leaf >> 24) & 0x7fu;
-        first_out = static_cast<uint32_t>(out.slot_object.size());
-        cnt_out = cnt;
-        for (uint32_t q = 0; q < cnt; ++q) out.slot_object.push_back(bin.slot_object[first + q]);
-    };
-    constexpr uint32_t kNone = 0xffffffffu;
-    uint32_t cur = bin.root_ref;
-    auto peel = [&](uint32_t leaf) {
-        uint32_t first, cnt;
-        take_leaf(leaf, first, cnt);
-        out.pre_leaf[out.n_pre_leaves++] = make_leaf_ref(first, cnt);
-    };
-    if (bin.nodes.empty()) { // the whole scene is one leaf
-        if (n) peel(bin.root_ref);
-        out.root = kNone;
-        return;
-    }
-    // leaves hanging directly off the top of the tree (the same spine rule as the binary walk)
-    while (!(cur & kLeafBit) && out.n_pre_leaves < 4u) {
-        const rtmi_bvh_node& nd = bin.nodes[cur];
-        const bool l0 = (nd.child[0] & kLeafBit) != 0u, l1 = (nd.child[1] & kLeafBit) != 0u;
-        if (l0 && l1 && out.n_pre_leaves + 2u <= 4u) {
-            peel(nd.child[0]);
-            peel(nd.child[1]);
-            cur = kNone;
-            break;
-        }
-        if (l0 == l1) break;
-        peel(l0 ? nd.child[0] : nd.child[1]);
-        cur = l0 ? nd.child[1] : nd.child[0];
-    }
-    if (cur == kNone) {
-        out.root = kNone;
-        return;
-    }
-    auto leaf_word = [](uint32_t first, uint32_t two_mask) { return first | (two_mask << 23); };
-    if (cur & kLeafBit) { // a single leaf is left: the walk starts (and ends) at a one-leaf group
-        uint32_t first, cnt;
-        take_leaf(cur, first, cnt);
-        if (cnt > 2u) throw std::runtime_error("4-wide tree: leaves hold at most two spheres");
-        out.root = 0x80000000u | leaf_word(first, cnt == 2u ? 1u : 0u) | (1u << 27);
-        return;
-    }
-    struct Child {
-        double lo[3], hi[3];
-        uint32_t ref;
-        double area() const {
-            const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-            return dx * dy + dy * dz + dz * dx;
-        }
-    };
-    auto child_of = [&](uint32_t b, int k) {
-        const rtmi_bvh_node& nd = bin.nodes[b];
-        Child c;
-        for (int a = 0; a < 3; ++a) { // exact in double: the box the binary walk tests is [ctr - half, ctr + half]
-            c.lo[a] = static_cast<double>(nd.ctr[k][a]) - static_cast<double>(nd.half[k][a]);
-            c.hi[a] = static_cast<double>(nd.ctr[k][a]) + static_cast<double>(nd.half[k][a]);
-        }
-        c.ref = nd.child[k];
-        return c;
-    };
-    struct Work {
-        uint32_t bin_node, index, level;
-    };
-    std::vector<Work> work;
-    out.nodes.emplace_back();
-    work.push_back({cur, 0u, 1u});
-    out.root = 0u;
-    for (size_t head = 0; head < work.size(); ++head) {
-        const Work w = work[head];
-        out.depth = std::max(out.depth, w.level);
-        std::vector<Child> ch = {child_of(w.bin_node, 0), child_of(w.bin_node, 1)};
-        while (ch.size() < 4u) {
-            int pick = -1;
-            double best = -1.0;
-            for (size_t i = 0; i < ch.size(); ++i) {
-                if (!(ch[i].ref & kLeafBit) && ch[i].area() > best) {
-                    best = ch[i].area();
-                    pick = static_cast<int>(i);
-                }
-            }
-            if (pick < 0) break;
-            const uint32_t b = ch[static_cast<size_t>(pick)].ref;
-            ch[static_cast<size_t>(pick)] = child_of(b, 0);
-            ch.push_back(child_of(b, 1));
-        }
-        std::stable_sort(ch.begin(), ch.end(), [](const Child& a, const Child& b) {
-            return ((a.ref & kLeafBit) != 0u) > ((b.ref & kLeafBit) != 0u); // leaves first
-        });
-        uint32_t k = 0;
-        while (k < ch.size() && (ch[k].ref & kLeafBit)) ++k;
-        const uint32_t m = static_cast<uint32_t>(ch.size()) - k;
-        const uint32_t first_internal = static_cast<uint32_t>(out.nodes.size());
-        out.nodes.resize(out.nodes.size() + m);
-        for (uint32_t j = 0; j < m; ++j) work.push_back({ch[k + j].ref, first_internal + j, w.level + 1u});
-        const uint32_t leaf_base = static_cast<uint32_t>(out.slot_object.size());
-        uint32_t two_mask = 0;
-        for (uint32_t i = 0; i < k; ++i) {
-            uint32_t first, cnt;
-            take_leaf(ch[i].ref, first, cnt);
-            if (cnt > 2u || cnt == 0u) throw std::runtime_error("4-wide tree: leaves hold one or two spheres");
-            if (cnt == 2u) two_mask |= 1u << i;
-        }
-        rtmi_bvh4_node nd{};
-        uint32_t q[6] = {0xffffffffu, 0u, 0xffffffffu, 0u, 0xffffffffu, 0u}; // lo bytes 255, hi bytes 0: children that do not exist
-        uint32_t exps = 0;
-        for (int a = 0; a < 3; ++a) {
-            double lo = std::numeric_limits<double>::infinity(), hi = -lo;
-            for (const Child& c : ch) {
-                lo = std::min(lo, c.lo[a]);
-                hi = std::max(hi, c.hi[a]);
-            }
-            float org = static_cast<float>(lo);
-            if (static_cast<double>(org) > lo) org = down(org);
-            const long double o = org;
-            int e = -126;
-            const long double ext = static_cast<long double>(hi) - o;
-            while (e < 127 && 255.0L * std::ldexp(1.0L, e) < ext) ++e;
-            for (;;) {
-                const long double sc = std::ldexp(1.0L, e);
-                bool ok = true;
-                uint32_t wl = 0xffffffffu, wh = 0u;
-                for (size_t i = 0; i < ch.size(); ++i) {
-                    long double ql = std::floor((static_cast<long double>(ch[i].lo[a]) - o) / sc);
-                    long double qh = std::ceil((static_cast<long double>(ch[i].hi[a]) - o) / sc);
-                    if (o + ql * sc > static_cast<long double>(ch[i].lo[a])) ql -= 1.0L;
-                    if (o + qh * sc < static_cast<long double>(ch[i].hi[a])) qh += 1.0L;
-                    if (ql < 0.0L) ql = 0.0L; // (org <= every lo: only a rounding artefact can get here)
-                    if (qh > 255.0L) {
-                        ok = false;
-                        break;
-                    }
-                    wl = (wl & ~(0xffu << (8u * i))) | (static_cast<uint32_t>(ql) << (8u * i));
-                    wh = (wh & ~(0xffu << (8u * i))) | (static_cast<uint32_t>(qh) << (8u * i));
-                }
-                if (ok) {
-                    q[2 * a] = wl;
-                    q[2 * a + 1] = wh;
-                    break;
-                }
-                if (++e > 127) throw std::runtime_error("4-wide tree: box extent beyond fp32");
-            }
-            nd.org[a] = org;
-            exps |= static_cast<uint32_t>(e + 127) << (8 * a);
-        }
-        nd.exps = exps;
-        nd.lo_x = q[0]; nd.hi_x = q[1]; nd.lo_y = q[2]; nd.hi_y = q[3]; nd.lo_z = q[4]; nd.hi_z = q[5];
-        const uint32_t valid = (1u << ch.size()) - 1u, imask = valid & ~((1u << k) - 1u);
-        nd.nodes = ((first_internal - k) & 0x00ffffffu) | (imask << 24) | (valid << 28);
-        nd.leaves = leaf_word(leaf_base, two_mask);
-        out.nodes[w.index] = nd;
-    }
-}
-
 } // namespace rtmi
-
-extern "C" int rtmi_bvh4_build(const rtmi_object* objects, uint32_t n_objects, rtmi_bvh4_node* nodes_out, uint32_t* n_nodes,
-                               uint32_t* slots_out, uint32_t* root_out, uint32_t* depth, uint32_t pre_leaves_out[4],
-                               uint32_t* n_pre_leaves, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,
-                               float* pad_floor) {
-    if (n_objects && !objects) {
-        set_error("rtmi_bvh4_build: null objects");
-        return RTMI_ERR_BAD_ARG;
-    }
-    if (n_objects >= 0x007fffffu) {
-        set_error("rtmi_bvh4_build: too many objects (leaf words hold 23-bit slots)");
-        return RTMI_ERR_UNSUPPORTED;
-    }
-    for (uint32_t i = 0; i < n_objects; ++i) {
-        const rtmi_object& o = objects[i];
-        if (!std::isfinite(o.center[0]) || !std::isfinite(o.center[1]) || !std::isfinite(o.center[2]) ||
-            !std::isfinite(o.radius)) {
-            set_error("rtmi_bvh4_build: object with a non-finite centre or radius");
-            return RTMI_ERR_BAD_ARG;
-        }
-    }
-    Bvh bvh;
-    Bvh4 b4;
-    try {
-        build_bvh(objects, n_objects, 2u, bvh);
-        build_bvh4(bvh, b4);
-    } catch (const std::bad_alloc&) {
-        set_error("rtmi_bvh4_build: out of host memory");
-        return RTMI_ERR_OOM;
-    } catch (const std::exception& e) {
-        set_error(std::string("rtmi_bvh4_build: ") + e.what());
-        return RTMI_ERR_INTERNAL;
-    } catch (...) {
-        set_error("rtmi_bvh4_build: unexpected exception");
-        return RTMI_ERR_INTERNAL;
-    }
-    if (n_nodes) *n_nodes = static_cast<uint32_t>(b4.nodes.size());
-    if (root_out) *root_out = b4.root;
-    if (depth) *depth = b4.depth;
-    if (n_pre_leaves) *n_pre_leaves = b4.n_pre_leaves;
-    if (pre_leaves_out) std::memcpy(pre_leaves_out, b4.pre_leaf, sizeof(b4.pre_leaf));
-    if (n_classes) *n_classes = bvh.n_pad_classes;
-    if (pad_eps) *pad_eps = bvh.pad_eps;
-    if (pad_floor) *pad_floor = bvh.pad_floor;
-    if (nodes_out && !b4.nodes.empty()) std::memcpy(nodes_out, b4.nodes.data(), b4.nodes.size() * sizeof(rtmi_bvh4_node));
-    if (slots_out && n_objects) std::memcpy(slots_out, b4.slot_object.data(), n_objects * sizeof(uint32_t));
-    if (pad_classes_out) std::memcpy(pad_classes_out, bvh.pad_classes, sizeof(bvh.pad_classes));
-    return RTMI_OK;
-}
 
 extern "C" int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size,
                               rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref,

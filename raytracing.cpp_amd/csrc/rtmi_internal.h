@@ -12,7 +12,6 @@ namespace rtmi {
 static_assert(sizeof(rtmi_object) == 24, "HittableObject layout (reference object.defs.hpp:30-57) is 24 bytes");
 static_assert(sizeof(rtmi_material) == 20, "Material layout (reference material.defs.hpp:49-55) is 20 bytes");
 static_assert(sizeof(rtmi_bvh_node) == 64, "BVH node is one 64-byte LDS record");
-static_assert(sizeof(rtmi_bvh4_node) == 48, "4-wide node is three 16-byte reads");
 static_assert(sizeof(rtmi_camera) == 100, "14 POD fields of RayTracingCore (reference core.hpp:19-32)");
 
 constexpr uint32_t kLeafBit = 0x80000000u;
@@ -44,20 +43,7 @@ struct Bvh {
     float pad_floor = 0.0f;
 };
 
-// The 4-wide tree with quantised child boxes that HBM-resident scenes are walked through (rtmi_bvh4_node), collapsed from
-// the binary SAH tree below its peeled leaves.
-struct Bvh4 {
-    std::vector<rtmi_bvh4_node> nodes;
-    std::vector<uint32_t> slot_object; // the 4-wide tree has its own slot order (the leaves of a node are consecutive)
-    uint32_t root = 0xffffffffu;       // node index | 0x80000000 + leaf word | 0xffffffff: nothing below the peeled leaves
-    uint32_t depth = 0;                // levels of 4-wide nodes on the longest path
-    uint32_t pre_leaf[4] = {};         // make_leaf_ref form
-    uint32_t n_pre_leaves = 0;
-};
-constexpr uint32_t kWalkDone4 = 0x00ffffffu; // "not walking" in the 4-wide walk's reference encoding
-
 void set_error(const std::string& msg);
-void build_bvh4(const Bvh& binary, Bvh4& out);
 void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& out);
 
 } // namespace rtmi

@@ -45,7 +45,7 @@ def gpu():
 
 
 @pytest.mark.parametrize("tuning", [dict(kernel=2), dict(kernel=2, wf_block_lanes=512, wf_slots=320, wf_refill=8),
-                                    dict(kernel=2, wf_refill=56, blocks_per_cu=1)])
+                                    dict(kernel=2, wf_refill=56, blocks_per_cu=1), dict(kernel=2, force_hbm_scene=1)])
 def test_queue_scheduled_kernel_matches_oracle(xpkg, ob, rtow, gpu, tuning):
     """rtmi_tuning::kernel = 2 (rtmi_wavefront.hip: path slots and rings in LDS, waves take homogeneous batches): same
     draw streams, same arithmetic -- the oracle's frame bit for bit, the oracle's work counters, for LDS- and

@@ -227,76 +227,3 @@ def test_row_block_sharding_covers_every_row_once(pkg, height, block, world):
                 stacked[r * plan.max_rows + loc] = y
                 loc += 1
     assert np.array_equal(stacked[plan.index], np.arange(height))
-
-
-def test_4_wide_tree_invariants(pkg, rtow):
-    """rtmi_bvh4_build: every object sits in exactly one slot; the leaves of a node are consecutive slots, its internal
-    children consecutive nodes, leaves come first; every child box (org + q * 2^e) contains the spheres below it; every
-    node is reachable exactly once."""
-    from tests.scenes import big_grid, random_spheres
-    worlds = [rtow[0], random_spheres(300, seed=2)[0], big_grid(30)[0], random_spheres(12, seed=3)[0]]
-    for objs in worlds:
-        b = pkg.bvh4_build(objs)
-        n = len(objs)
-        assert sorted(b["slots"].tolist()) == list(range(n))
-        seen_slot = np.zeros(n, bool)
-        for leaf in b["pre_leaves"]:
-            first, cnt = int(leaf) & 0xffffff, (int(leaf) >> 24) & 0x7f
-            assert not seen_slot[first:first + cnt].any()
-            seen_slot[first:first + cnt] = True
-        nodes = b["nodes"]
-        seen_node = np.zeros(len(nodes), bool)
-
-        def box_of(nd, i):
-            lo, hi = np.zeros(3), np.zeros(3)
-            for a in range(3):
-                s = 2.0 ** (((int(nd["exps"]) >> (8 * a)) & 0xff) - 127)
-                lo[a] = float(nd["org"][a]) + s * ((int(nd["q"][2 * a]) >> (8 * i)) & 0xff)
-                hi[a] = float(nd["org"][a]) + s * ((int(nd["q"][2 * a + 1]) >> (8 * i)) & 0xff)
-            return lo, hi
-
-        def visit(idx, depth):
-            """returns the true bounds of the spheres below node idx; every child box must contain what is below it (the
-            quantised boxes need not nest: each only has to be a superset of the binary tree's box)"""
-            assert not seen_node[idx] and depth <= b["depth"]
-            seen_node[idx] = True
-            nd = nodes[idx]
-            valid, imask = int(nd["nodes"]) >> 28, (int(nd["nodes"]) >> 24) & 15
-            k = 0
-            while (valid >> k) & 1 and not (imask >> k) & 1:
-                k += 1
-            assert valid in (3, 7, 15) and imask == valid & ~((1 << k) - 1)  # leaves first, no holes
-            slot = int(nd["leaves"]) & 0x7fffff
-            two = (int(nd["leaves"]) >> 23) & 15
-            all_lo, all_hi = np.full(3, np.inf), np.full(3, -np.inf)
-            for i in range(4):
-                if not (valid >> i) & 1:
-                    continue
-                clo, chi = box_of(nd, i)
-                if i < k:
-                    cnt = 1 + ((two >> i) & 1)
-                    assert not seen_slot[slot:slot + cnt].any()
-                    seen_slot[slot:slot + cnt] = True
-                    slo, shi = np.full(3, np.inf), np.full(3, -np.inf)
-                    for q in range(slot, slot + cnt):
-                        o = objs[b["slots"][q]]
-                        r = abs(float(o["radius"]))
-                        c = o["center"].astype(np.float64)
-                        slo, shi = np.minimum(slo, c - r), np.maximum(shi, c + r)
-                    slot += cnt
-                else:
-                    slo, shi = visit((int(nd["nodes"]) + i) & 0xffffff, depth + 1)
-                assert (clo <= slo).all() and (chi >= shi).all()
-                all_lo, all_hi = np.minimum(all_lo, slo), np.maximum(all_hi, shi)
-            return all_lo, all_hi
-
-        root = b["root"]
-        if root == 0xffffffff:
-            assert len(nodes) == 0
-        elif root & 0x80000000:
-            slot, two = root & 0x7fffff, (root >> 23) & 15
-            cnt = 1 + (two & 1)
-            seen_slot[slot:slot + cnt] = True
-        else:
-            visit(root, 1)
-        assert seen_slot.all() and seen_node.all()

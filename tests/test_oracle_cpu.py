@@ -395,30 +395,3 @@ def test_regression_thumbnails(ob, name):
     cam = ob.camera_setup(ob.camera_params(**kw))
     _, rgba = ob.render_rect_counter(cam, objs, mats, SEED, 0, 0, cam.img_width, cam.img_height, nthreads=8)
     assert np.array_equal(rgba_to_rgb(rgba), read_png(os.path.join(GOLDEN, name + ".png")))
-
-
-def test_oracle_walk_of_the_4_wide_tree_equals_linear_scan(pkg, ob, rtow):
-    """The product's 4-wide tree of HBM-resident scenes (rtmi_bvh4_build: child boxes as 8-bit offsets on the node origin,
-    rounded outwards; leaves hanging off the top peeled) walked by the oracle: the linear scan's image bit for bit, for the
-    RTOW scene, worlds so small that the peeled leaves are the whole tree, and a jittered grid over a huge ground sphere;
-    and about as many box tests per segment as the binary tree it was collapsed from."""
-    from tests.scenes import big_grid, random_spheres, three_spheres
-    cases = [("rtow", rtow[0], rtow[1], dict(image_width=80, samples_per_pixel=3, max_depth=50))]
-    for n in (1, 2, 3, 5, 9, 40):
-        o, m = random_spheres(n, seed=n)
-        cases.append((f"random({n + 1})", o, m, dict(image_width=48, samples_per_pixel=2, max_depth=20)))
-    o, m = three_spheres()
-    cases.append(("three", o, m, dict(image_width=48, samples_per_pixel=2, max_depth=8)))
-    o, m, kw = big_grid(40)
-    cases.append(("grid(40)", o, m, dict(kw, image_width=48, samples_per_pixel=2)))
-    for name, objs, mats, kw in cases:
-        cam = ob.camera_setup(ob.camera_params(**kw))
-        b4 = pkg.bvh4_build(objs)
-        want, want8 = ob.render_rect_counter(cam, objs, mats, 5, 0, 0, cam.img_width, cam.img_height, nthreads=8)
-        got, got8, c4 = ob.render_rect_counter(cam, objs, mats, 5, 0, 0, cam.img_width, cam.img_height, nthreads=8, counters=True, bvh=b4)
-        assert np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(want).view(np.uint32)), name
-        assert np.array_equal(got8, want8), name
-        if len(objs) > 30:
-            _, _, c2 = ob.render_rect_counter(cam, objs, mats, 5, 0, 0, cam.img_width, cam.img_height, nthreads=8, counters=True,
-                                              bvh=pkg.bvh_build(objs))
-            assert c4["segments"] == c2["segments"] and c4["node_tests"] < 1.2 * c2["node_tests"], name

@@ -24,7 +24,7 @@ else:
     objs, mats, kw = pkg.workloads.big_grid(316)
     kw.update(image_width=w, samples_per_pixel=spp)
     cam = pkg.camera_setup(pkg.camera_params(**kw))
-scenes = [pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=v or None) for v in variants]
+scenes = [pkg.Scene(cam, objs, mats, tuning=v or None) for v in variants]  # (RTMI_ACCEL_AUTO: the library's own choice)
 res = [[] for _ in variants]
 ref = None
 for rnd in range(3):
