@@ -476,7 +476,7 @@ def main(argv=None):
             try:
                 for tj in json.load(open(tpath)).get("entries", []):
                     if (tj.get("config") == args.config and tj.get("width") == W and tj.get("spp") == spp
-                            and tj.get("n_gpus") == n_gpus and args.accel == "bvh"):
+                            and tj.get("n_gpus") == n_gpus and tj.get("accel", "bvh") == args.accel):
                         traffic = tj.get("bytes_per_launch")
                         traffic_note = tj.get("note")
             except Exception:

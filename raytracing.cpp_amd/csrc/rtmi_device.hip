@@ -728,6 +728,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
         PB(9, phase == PH_SHADE && t.best < kBlackSample);
         PB(14, phase == PH_SHADE && t.best == ~0u);
         PB(15, phase == PH_SHADE && t.best == ~0u && (natt != 0u || run_n != 0u));
+#if defined(RTMI_PROF) && RTMI_PROF == 2
+        { // (census votes are taken outside the divergent code they describe: inside it the compiler may move them)
+            const uint32_t kind_c = (phase == PH_SHADE && t.best < kBlackSample) ? lds_aux[t.best].w : 3u;
+            PB(10, kind_c == 0u);
+            PB(11, kind_c == 1u);
+            PB(12, kind_c == 2u);
+        }
+#endif
         PB(22, rq == RQ_WORD || (phase == PH_SHADE && t.best == ~0u)); // the shared normalize(ray.direction)
         if (phase == PH_SHADE) {
             bool ended = false;
@@ -759,9 +767,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                 const uint32_t kind = araw.w;
                 V3 sd = mk(0.0f, 0.0f, 0.0f);
                 bool scattered = true;
-                PB(10, kind == 0u);
-                PB(11, kind == 1u);
-                PB(12, kind == 2u);
                 if (kind != 2u) {
                     // Lambertian (material.defs.cc:31-42) and Metallic (:44-55) share ONE rejection loop for their
                     // random_unit_vector(): the wave pays the longest run of rejections once, not once per material.
