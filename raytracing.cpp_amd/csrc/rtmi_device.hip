@@ -685,6 +685,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             if (ballot(phase == PH_TRAV) != 0ull) {
                 if (phase == PH_TRAV) {
                     uint32_t i = 0;
+                    const Recip ra = recip_for(t.a); // shared by every root of this segment
                     for (; i + 4u <= P.n_slots; i += 4u) { // four broadcast reads in flight, four discriminants, then the rare roots
                         const uint4 r0 = lds_spheres[i], r1 = lds_spheres[i + 1u], r2 = lds_spheres[i + 2u], r3 = lds_spheres[i + 3u];
                         float h0, h1, h2, h3, d0, d1, d2, d3;
@@ -693,16 +694,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                         sphere_delta(r2, t, h2, d2);
                         sphere_delta(r3, t, h3, d3);
                         if (fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) { // insertion order, as the reference scans
-                            if (d0 >= 0.0f) sphere_root(h0, d0, t, i, t.tbest, t.best);
-                            if (d1 >= 0.0f) sphere_root(h1, d1, t, i + 1u, t.tbest, t.best);
-                            if (d2 >= 0.0f) sphere_root(h2, d2, t, i + 2u, t.tbest, t.best);
-                            if (d3 >= 0.0f) sphere_root(h3, d3, t, i + 3u, t.tbest, t.best);
+                            if (d0 >= 0.0f) sphere_root(h0, d0, t, ra, i, t.tbest, t.best);
+                            if (d1 >= 0.0f) sphere_root(h1, d1, t, ra, i + 1u, t.tbest, t.best);
+                            if (d2 >= 0.0f) sphere_root(h2, d2, t, ra, i + 2u, t.tbest, t.best);
+                            if (d3 >= 0.0f) sphere_root(h3, d3, t, ra, i + 3u, t.tbest, t.best);
                         }
                     }
                     for (; i < P.n_slots; ++i) {
                         float h0, d0;
                         sphere_delta(lds_spheres[i], t, h0, d0);
-                        if (d0 >= 0.0f) sphere_root(h0, d0, t, i, t.tbest, t.best);
+                        if (d0 >= 0.0f) sphere_root(h0, d0, t, ra, i, t.tbest, t.best);
                     }
                     if (STATS) st_sphere += P.n_slots;
                     phase = PH_SHADE;

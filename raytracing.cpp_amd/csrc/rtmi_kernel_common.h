@@ -468,10 +468,17 @@ DEV void sphere_delta(const uint4 raw, const Trav& t, float& h, float& delta) {
     const float c = vdot(oc, oc) - __uint_as_float(raw.w);
     delta = h * h - t.a * c;
 }
-DEV void sphere_root(float h, float delta, const Trav& t, uint32_t slot, float& tbest, uint32_t& best) {
-    const float sqrtd = __builtin_sqrtf(delta);
-    float root = (h - sqrtd) / t.a;
-    if (!(root > 0.0001f)) root = (h + sqrtd) / t.a;
+DEV void sphere_root(float h, float delta, const Trav& t, const Recip& ra, uint32_t slot, float& tbest, uint32_t& best) {
+    // the in-range cores of the square-root and division expansions on a reciprocal shared by the segment's roots (as in
+    // the walk, below): inside the box of config 5 every ray's line meets four or five of the seven spheres, and the full
+    // expansions (16 + 2 x 11 instructions per root) were a third of the scan
+    const float sqrtd = sqrt_shared(delta);
+    float root = div_in_range(h - sqrtd, ra);
+    if (!(root > 0.0001f)) root = div_in_range(h + sqrtd, ra);
+    if (!(ra.in_range && __builtin_fabsf(root) < 0x1p40f)) { // out of range (or NaN): the full expansion
+        root = (h - sqrtd) / t.a;
+        if (!(root > 0.0001f)) root = (h + sqrtd) / t.a;
+    }
     if (root > 0.0001f && root < tbest) { // strict <: the first inserted object wins a tie (object.defs.cc:73)
         tbest = root;
         best = slot;

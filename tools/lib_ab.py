@@ -47,7 +47,7 @@ for rnd in range(2):
             if objs is None:
                 objs, mats = pkg.make_world_spheres(12345)
             cam = pkg.camera_setup(pkg.camera_params(image_width=w, samples_per_pixel=spp, max_depth=50))
-        with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=tuning or None) as sc:
+        with pkg.Scene(cam, objs, mats, tuning=tuning or None) as sc:  # RTMI_ACCEL_AUTO
             if rnd == 0:
                 print(f"      {name}: {sc.launch_info()}")
             ms = []
