@@ -273,8 +273,17 @@ def main(argv=None):
     gather_ms = []
     t_setup = time.perf_counter()
     if args.single_process:
-        frame_obj = pkg.Frame(cam, objs, mats, devices=tuple(range(n_gpus)), block_rows=BLOCK_ROWS, accel=accel,
-                              force_rccl=args.force_dist)
+        # (librccl prints a version banner on stdout when the first communicator is created: this process owes its stdout
+        # ONE JSON line, so the banner goes to stderr)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            frame_obj = pkg.Frame(cam, objs, mats, devices=tuple(range(n_gpus)), block_rows=BLOCK_ROWS, accel=accel,
+                                  force_rccl=args.force_dist)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         scene = None
 
         def step():
