@@ -20,8 +20,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def xpkg():
-    """A second instance of the package module bound to librtmi_exp.so."""
+def xpkg(gpu):
+    """A second instance of the package module bound to librtmi_exp.so.  (After `gpu`: torch brings its own HIP runtime, and a
+    process that loads /opt/rocm's copy first ends up with two of them and no device.)"""
     pkg_dir = os.path.join(ROOT, "raytracing.cpp_amd")
     if not os.path.exists(os.path.join(pkg_dir, "librtmi_exp.so")):
         pytest.skip("librtmi_exp.so not built (build_library(experimental=True))")
