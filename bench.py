@@ -457,8 +457,10 @@ def main(argv=None):
                 worst = max(worst, float(d.max()))
             out["parity_check"] = {"pixels": n_chk, "max_abs_diff_vs_oracle": worst,
                                    "oracle": "linear scan" if obvh is None else "instrumented BVH walk (== linear scan, tests)"}
-        bvh = pkg.bvh_build(objs) if args.accel == "bvh" else None
-        if bvh is not None:
+        # the tree the kernel walks (the library's default leaf size depends on where the scene lives)
+        bvh = None
+        if args.accel == "bvh":
+            bvh = scene.bvh() if scene is not None else pkg.bvh_build(objs, 4 if len(objs) > 0x2000 else 2)
             bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
         ctr_stride = 24
         ctr = {"samples": 0, "segments": 0, "sphere_tests": 0, "node_tests": 0, "hit_lambertian": 0, "hit_metallic": 0}

@@ -129,7 +129,7 @@ typedef struct rtmi_tuning {
 typedef struct rtmi_scene_options {
     uint32_t struct_size;  /* = sizeof(rtmi_scene_options) */
     uint32_t accel;        /* rtmi_accel */
-    uint32_t leaf_size;    /* BVH: max spheres per leaf (0 = default) */
+    uint32_t leaf_size;    /* BVH: max spheres per leaf, 1..4 (0 = default: 2, or 4 for more than 8192 objects -- trees that stay in HBM) */
     int32_t device;        /* HIP device ordinal, -1 = the caller's current device (also when options == NULL) */
     uint32_t collect_stats;/* nonzero: kernels also count segments / node tests / sphere tests */
     uint32_t reserved[3];

@@ -583,7 +583,7 @@ extern "C" int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, ui
     }
     Bvh bvh;
     try {
-        build_bvh(objects, n_objects, leaf_size ? leaf_size : 2u, bvh);
+        build_bvh(objects, n_objects, leaf_size ? leaf_size : (n_objects > 0x2000u ? 4u : 2u), bvh); // (the default of rtmi_scene_create)
     } catch (const std::bad_alloc&) {
         set_error("rtmi_bvh_build: out of host memory");
         return RTMI_ERR_OOM;
