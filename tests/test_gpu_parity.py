@@ -632,6 +632,18 @@ def test_multi_device_frame_over_rccl(pkg, rtow, gpu):
             rgb, rgba = f.render(5)
             rgb2, _ = f.render(5)
         assert rgb.tobytes() == ref.tobytes() and np.array_equal(rgba, ref8) and rgb2.tobytes() == ref.tobytes(), n
+    # the bench harness over the same path: one process driving two devices (rtmi_frame_*), and two ranks under
+    # torch.distributed.run with the "nccl" backend
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "2", "--width", "200", "--spp", "8",
+            "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-linear-scan"]
+    for extra in (["--single-process"], []):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        doc = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert doc["rccl_ranks"] == 2 and doc["n_gpus"] == 2 and doc["value"] > 0, doc
 
 
 def test_scene_just_below_the_lds_limit_keeps_two_workgroups_per_cu(pkg, gpu):
