@@ -11,22 +11,24 @@
 // Design (MI355X-first):
 //  * persistent lanes: a work item is a chunk of consecutive samples of one pixel; lanes take items from per-wave
 //    pools refilled 64 at a time from a global counter (ballot + prefix popcount), store one 16-byte record per
-//    sample, and rtmi_resolve_kernel adds the records up in sample order (the reference's sequential fp32 sum,
+//    sample, and a resolve pass adds the records up in sample order (the reference's sequential fp32 sum,
 //    core.cc:260-263).
 //  * recursion flattened: a lane is a small state machine FETCH -> GEN -> BEGIN -> TRAVERSE -> SHADE; the attenuation
-//    chain A1*(A2*(...*sky)) of the recursive compute_color is replayed innermost-first at path end from run-length
-//    encoded material handles kept in LDS, so the colour is bit-identical to the recursion.
+//    chain A1*(A2*(...*sky)) of the recursive compute_color is multiplied innermost-first, so the colour is bit-identical
+//    to the recursion: from run-length encoded material handles at path end, or -- where the whole chain fits LDS as a
+//    packed string of handles -- by the resolve pass, one lane per sample (rtmi_resolve_chain_kernel).
 //  * traversal: per iteration the wave votes between a node step and a leaf step; it leaves the loop as soon as
 //    enough lanes wait for shading (ballot/popcount), shades them, refills them and re-enters traversal.  The node
-//    steps of LDS-resident trees are one hand-scheduled gfx950 loop (walk_nodes_lds); the C++ node step beside it
-//    serves the HBM-resident, statistics and stamp variants.
+//    steps are hand-scheduled gfx950 loops (walk_nodes_lds for trees staged into LDS, walk_nodes_hbm for trees read
+//    through the caches); the C++ node step beside them serves the statistics and stamp variants.
+//  * scenes of up to 24 spheres are scanned linearly, as the reference does (measured crossover).
 //  * random_unit_vector: the owner lane makes its first two attempts, the wave shares the retries (coop_draws).
 //  * the reference's fp32 divisions and square roots run as the in-range cores of the compiler's own expansions
 //    (bit-identical, a third of the instructions), the full expansions behind a branch for operands out of range.
 //  * scene (BVH nodes, spheres, materials) staged once per workgroup into LDS with coalesced 16-byte loads; the
 //    per-lane traversal stack lives in LDS too.  Scenes that do not fit stay in HBM (BIG variant) behind L2 / Infinity Cache.
-//  * counter RNG: a block function (pcg4d; Philox4x32 in the A/B) of (seed, draw block, sample, pixel): the image does not depend on
-//    tiling, row sharding or GPU count.
+//  * counter RNG: a block function (pcg4d; Philox4x32 in the A/B) of (draw block, sample, pixel) keyed by a bijective mix
+//    of the seed: the image does not depend on tiling, row sharding or GPU count.
 //  * arithmetic of the reference path is kept operation for operation (no FMA contraction, IEEE sqrt/div); only the
 //    BVH slab tests, which the reference does not have, use FMA.
 #include <hip/hip_runtime.h>
