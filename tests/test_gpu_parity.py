@@ -224,6 +224,40 @@ def test_packed_and_run_length_attenuation_chains(pkg, ob, rtow, gpu):
             _assert_frames_equal(frame, want)
 
 
+def test_packed_chain_word_geometry(pkg, ob, gpu):
+    """The packed chain's geometry follows the material count and the bounce limit: 1 bit a handle (32 to a word) for one or
+    two materials up to 9 bits (3 to a word), slots of 4 to 16 words, chains that end exactly at a word boundary or one
+    handle past it -- every combination against the oracle, with the packed form actually in use."""
+    rng = np.random.default_rng(11)
+    for n_mats, depth in ((1, 33), (2, 64), (3, 16), (4, 17), (5, 10), (8, 11), (9, 8), (17, 7), (33, 30), (100, 50), (300, 40)):
+        n = max(n_mats, 12)
+        objs = np.zeros(n + 1, pkg.OBJECT_DTYPE)
+        mats = np.zeros(n_mats, pkg.MATERIAL_DTYPE)
+        mats["kind"] = 0
+        mats["p"][:, :3] = rng.uniform(0.6, 0.99, (n_mats, 3)).astype(np.float32)  # bright walls: long chains reach the sky
+        if n_mats > 2:
+            mats["kind"][1] = 1
+            mats["p"][1, 3] = 0.1
+        objs["center"][:n] = rng.uniform(-2.5, 2.5, (n, 3)).astype(np.float32)
+        objs["radius"][:n] = rng.uniform(0.4, 1.1, n).astype(np.float32)
+        objs["material"][:n] = rng.integers(0, n_mats, n)
+        objs["center"][n] = (0.0, -1001.5, 0.0)
+        objs["radius"][n] = 1000.0
+        objs["material"][n] = n_mats - 1
+        kw = dict(aspect_ratio=1.0, image_width=40, samples_per_pixel=12, max_depth=depth, vertical_fov=55.0, defocus_angle=0.0,
+                  focus_distance=1.0, lookfrom=(0.0, 1.0, 7.0), lookat=(0.0, 0.0, 0.0), world_up=(0.0, 1.0, 0.0))
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        want, want8 = ob.render_rect_counter(ocam, objs, mats, 17, 0, 0, 40, 40, nthreads=8)
+        for accel, _ in _both(pkg):
+            with pkg.Scene(cam, objs, mats, accel=accel) as s:
+                bits = max(1, int(np.ceil(np.log2(max(2, n_mats)))))
+                words = -(-depth // (32 // bits))
+                assert s.launch_info()["packed_chains"] == (words + 3) // 4 * 4, (n_mats, depth)
+                rgb, rgba = s.render_rows(0, 40, 17)
+            _assert_frames_equal(rgb, want)
+            assert np.array_equal(rgba, want8), (n_mats, depth)
+
+
 def test_random_scenes_and_cameras(pkg, ob, gpu):
     """Forty random worlds -- overlapping and nested spheres, cameras inside spheres, fuzz > 1 (clamped at
     construction), refraction indices below 1, huge and tiny radii, shared material handles -- through both accel
