@@ -191,9 +191,10 @@ def lib():
     L.rtmi_frame_render_device.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
     L.rtmi_frame_get_timing.argtypes = [vp, C.POINTER(FrameTiming)]
     L.rtmi_frame_rccl_ranks.argtypes = [vp, C.POINTER(C.c_uint32)]
-    L.rtmi_frame_get_scene.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+    if hasattr(L, "rtmi_frame_get_scene"):  # (absent from older builds that tools/ A/B against the current one)
+        L.rtmi_frame_get_scene.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     for name in EXPORTS:
-        if name not in ("rtmi_last_error", "rtmi_version", "rtmi_scene_destroy", "rtmi_frame_destroy"):
+        if name not in ("rtmi_last_error", "rtmi_version", "rtmi_scene_destroy", "rtmi_frame_destroy") and hasattr(L, name):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
