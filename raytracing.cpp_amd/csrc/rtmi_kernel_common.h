@@ -183,7 +183,8 @@ DEV float vdot(V3 a, V3 b) { // glm::dot: t = a*b; t.x + t.y + t.z
     return (tx + ty) + tz;
 }
 DEV float sqrt_shared(float x);
-DEV V3 vnormalize(V3 v) { return vscale(v, 1.0f / sqrt_shared(vdot(v, v))); } // v * inversesqrt(dot(v,v))
+DEV float recip_shared(float den);
+DEV V3 vnormalize(V3 v) { return vscale(v, recip_shared(sqrt_shared(vdot(v, v)))); } // v * inversesqrt(dot(v,v)) = v * (1.0f / sqrt)
 DEV V3 vreflect(V3 I, V3 N) { return vsub(I, vscale(vscale(N, vdot(N, I)), 2.0f)); }
 DEV V3 vrefract(V3 I, V3 N, float eta) {
     const float d = vdot(N, I);
@@ -235,6 +236,17 @@ DEV float sqrt_shared(float x) {
     if (!(x >= 0x1p-90f && x <= 0x1p90f)) { // (also NaN, 0, negative: the full expansion)
         asm volatile("" : "+v"(x)); // a real branch: left alone the compiler evaluates both square roots and selects
         q = __builtin_sqrtf(x);
+    }
+    return q;
+}
+
+// 1.0f / den: the in-range core of the division expansion, the full expansion for denominators out of range
+DEV float recip_shared(float den) {
+    const Recip r = recip_for(den);
+    float q = div_in_range(1.0f, r);
+    if (!r.in_range) {
+        asm volatile("" : "+v"(den)); // a real branch (see sqrt_shared)
+        q = 1.0f / den;
     }
     return q;
 }
@@ -293,14 +305,17 @@ DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t
     }
     r.w0 = c0; r.w1 = c1; r.w2 = c2; r.w3 = c3;
 }
+// (x + y * w compiles to v_mad_u64_u32; forcing v_mul_lo_u32 + v_add_u32 -- 7.4 issue cycles against 9.2 in the micro-benchmark --
+// made the frame 2 % slower: 132.0 against 129.4 ms)
+DEV uint32_t muladd(uint32_t a, uint32_t b, uint32_t c) { return a * b + c; }
 DEV void pcg4d(uint32_t x, uint32_t y, uint32_t z, uint32_t w, Blk& r) {
     x = x * 1664525u + 1013904223u;
     y = y * 1664525u + 1013904223u;
     z = z * 1664525u + 1013904223u;
     w = w * 1664525u + 1013904223u;
-    x += y * w; y += z * x; z += x * y; w += y * z;
+    x = muladd(y, w, x); y = muladd(z, x, y); z = muladd(x, y, z); w = muladd(y, z, w);
     x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
-    x += y * w; y += z * x; z += x * y; w += y * z;
+    x = muladd(y, w, x); y = muladd(z, x, y); z = muladd(x, y, z); w = muladd(y, z, w);
     x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
     r.w0 = x; r.w1 = y; r.w2 = z; r.w3 = w;
 }
