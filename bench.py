@@ -304,6 +304,9 @@ def main(argv=None):
         rgb = local[:n_px * 3].view(plan.max_rows, W, 3)
         rgba = local[n_px * 3:].view(torch.int32).view(plan.max_rows, W, 1)
 
+        gathered = torch.empty(world * n_px * 4, dtype=torch.float32, device=dev) if rank == 0 else None
+        gathered_parts = list(gathered.view(world, n_px * 4).unbind(0)) if rank == 0 else None
+
         def split(parts):
             """[world * n_px * 4] gathered floats -> (rgb frame, rgba frame) in scanline order"""
             per = parts.view(world, n_px * 4)
@@ -324,9 +327,9 @@ def main(argv=None):
                 got = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, got, dst=0)
                 return split(torch.cat(got).to(dev)) if rank == 0 else (None, None)
-            got = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-            dist.gather(local, got, dst=0)  # the one RCCL collective of a frame
-            return split(torch.cat(got)) if rank == 0 else (None, None)
+            # the one RCCL collective of a frame, straight into one preallocated buffer on rank 0 (rank-major slices)
+            dist.gather(local, gathered_parts, dst=0)
+            return split(gathered) if rank == 0 else (None, None)
 
     def sync():
         torch.cuda.synchronize(dev)
