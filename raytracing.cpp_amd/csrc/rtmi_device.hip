@@ -852,12 +852,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                         const uint32_t e = lds_att[(q & 3u) * blockDim.x + threadIdx.x];
                         color = att_apply(color, e & 0xffffu, e >> 16);
                     }
+                    // (the strip is read back one block ahead of the multiplies: the next block's load is in flight while
+                    // the four runs of this one are applied)
+                    const uint4* strip = reinterpret_cast<const uint4*>(P.att_stack) + (size_t)glane * att_blocks;
+                    uint4 blk = full != 0u ? strip[full - 1u] : make_uint4(0u, 0u, 0u, 0u);
                     for (uint32_t b = full; b-- > 0u;) {
-                        const uint4 blk = reinterpret_cast<const uint4*>(P.att_stack)[(size_t)glane * att_blocks + b];
-                        color = att_apply(color, blk.w & 0xffffu, blk.w >> 16);
-                        color = att_apply(color, blk.z & 0xffffu, blk.z >> 16);
-                        color = att_apply(color, blk.y & 0xffffu, blk.y >> 16);
-                        color = att_apply(color, blk.x & 0xffffu, blk.x >> 16);
+                        const uint4 cur_blk = blk;
+                        if (b != 0u) blk = strip[b - 1u];
+                        color = att_apply(color, cur_blk.w & 0xffffu, cur_blk.w >> 16);
+                        color = att_apply(color, cur_blk.z & 0xffffu, cur_blk.z >> 16);
+                        color = att_apply(color, cur_blk.y & 0xffffu, cur_blk.y >> 16);
+                        color = att_apply(color, cur_blk.x & 0xffffu, cur_blk.x >> 16);
                     }
                 } else {
                     for (uint32_t q = natt; q-- > 0u;) {
