@@ -357,6 +357,7 @@ DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // `tbl` is 64 bytes of LDS private to the wave.
 enum : uint32_t { RQ_NONE = 0, RQ_UNIT = 1, RQ_WORD = 2 };
 constexpr int kSelfAttempts = 2; // measured on config 3: 0 -> 159.4 ms, 1 -> 153.3, 2 -> 152.5, 3 -> 154.3
+constexpr uint32_t kThirdAttemptLanes = 12;
 
 // (an LDS-qualified pointer: through a generic one these accesses become flat_* instructions with full waits)
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -365,10 +366,13 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl PB_ARGS) {
     if (code == RQ_UNIT) rng.k = (rng.k + 3u) & ~3u; // attempts are block aligned
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     bool pending = code != RQ_NONE;
-#pragma unroll 1
     PB(7, code == RQ_WORD);
     ISA_MARK("coop-owner");
-    for (int self = 0; self < kSelfAttempts; ++self) {
+    // (one more owner attempt when more than kThirdAttemptLanes lanes are still without a vector after the first two -- waves
+    // whose lanes nearly all shade Lambertian hits, the box of config 5: 14 of 63 -- is cheaper than the larger shared pass it
+    // replaces: -1.6 % there, +-0 on config 3 where 9 lanes are left on average; threshold 8: -0.9 % / +0.5 %)
+    for (int self = 0; self < kSelfAttempts + 1; ++self) {
+        if (self == kSelfAttempts && (uint32_t)__popcll(ballot(pending)) <= kThirdAttemptLanes) break;
         PB(4 + (self ? 1 : 0), pending);
         if (pending) {
             Blk tmp;
