@@ -227,3 +227,23 @@ def test_row_block_sharding_covers_every_row_once(pkg, height, block, world):
                 stacked[r * plan.max_rows + loc] = y
                 loc += 1
     assert np.array_equal(stacked[plan.index], np.arange(height))
+
+
+def test_header_is_plain_c_and_every_prototype_is_exported(pkg, tmp_path):
+    """include/rtmi.h is the C-ABI: it compiles as C99 (-pedantic -Werror) with the record sizes the reference's layouts give,
+    and every function it declares is a symbol of librtmi.so and in the binding's export list."""
+    import subprocess
+    src = tmp_path / "hc.c"
+    src.write_text('#include "rtmi.h"\n'
+                   'int main(void) { return (sizeof(rtmi_object) == 24 && sizeof(rtmi_material) == 20 && sizeof(rtmi_camera) == 100\n'
+                   '                         && sizeof(rtmi_bvh_node) == 64 && sizeof(rtmi_launch_info) == 40 && sizeof(rtmi_tuning) == 64) ? 0 : 1; }\n')
+    exe = tmp_path / "hc"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+    header = open(os.path.join(ROOT, "include", "rtmi.h")).read()
+    protos = set(re.findall(r"^(?:int|void|const char\*)\s+(rtmi_[a-z0-9_]+)\(", header, flags=re.M))
+    assert protos == set(pkg.EXPORTS), protos ^ set(pkg.EXPORTS)
+    lib = pkg.lib()
+    for name in protos:
+        getattr(lib, name)
