@@ -108,7 +108,10 @@ typedef struct rtmi_tuning {
     uint32_t block_lanes;       /* lanes per workgroup, multiple of 64 (default 768: 2 x 768 per CU = 6 waves per SIMD) */
     uint32_t blocks_per_cu;     /* cap on resident workgroups per CU (default: the occupancy query) */
     uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 52) */
-    uint32_t reserved0;         /* (was drain_wait_thresh: the deferred-path queue of rounds 1-2 is gone) ignored */
+    uint32_t pad_mode;          /* BVH box pad per ray segment: 1 = the class pad of rounds 1-3 (from the farthest centre of each
+                                 * radius class), 2 = that pad bounded by the reach of the segment, 0 = default: 2 on scenes
+                                 * much wider than their spheres (where it pays), else 1; same image in every mode.
+                                 * (This slot was drain_wait_thresh until round 2 and ignored in round 3.) */
     int32_t chunk_samples;      /* samples per work item: 0 = auto, -1 = whole pixels (no sample records), n > 0 = n */
     int32_t chain_mode;         /* attenuation chains: 0 = auto (packed strings of material handles in LDS, multiplied by the
                                  * resolve pass, when they fit next to the scene; else run-length encoded runs with per-lane
@@ -117,13 +120,11 @@ typedef struct rtmi_tuning {
     uint32_t sample_buf_mb;     /* cap on the sample-record buffer in MiB (default 24576); larger calls run in row bands */
     uint32_t force_hbm_scene;   /* nonzero: leave the scene in HBM even when it fits LDS (the config-4 path) */
     uint32_t top_down;          /* nonzero: hand out tiles top row first instead of bottom row first */
-    uint32_t kernel;            /* BVH scenes: 0 = library default, 1 = round-based kernel, 2 = queue-scheduled kernel
-                                 * (an experiment that lost on every measured workload: RTMI_ERR_UNSUPPORTED unless the
-                                 * library was built with -DRTMI_EXPERIMENTAL, which rtmi_version() then reports) */
-    uint32_t wf_block_lanes;    /* queue-scheduled kernel: lanes per workgroup (default 1024: one workgroup per CU) */
-    uint32_t wf_slots;          /* its path slots per workgroup (default: as many as LDS holds, at most 2 per lane) */
-    uint32_t wf_refill;         /* idle lanes at which a traversing wave takes new rays (default 24) */
-    uint32_t reserved[1];
+    uint32_t kernel;            /* 0 / 1 = the round-based kernel; 2 asked for round 2's queue-scheduled kernel (an experiment
+                                 * that lost on every measured workload, removed in round 4): RTMI_ERR_UNSUPPORTED */
+    uint32_t reserved3[3];      /* (were wf_block_lanes / wf_slots / wf_refill, the geometry of that kernel) ignored */
+    uint32_t lds_top_nodes;     /* HBM-resident trees: how many breadth-first nodes of the top of the tree each workgroup
+                                 * stages into LDS (0 = default: as many as fit next to the stacks; 1 = none) */
 } rtmi_tuning;
 
 typedef struct rtmi_scene_options {
@@ -205,7 +206,7 @@ int rtmi_scene_get_accel(const rtmi_scene* scene, uint32_t* accel_out);
 /* How rtmi_render_* will launch the trace kernel for this scene (what the tuning and the scene's size resolved to). */
 typedef struct rtmi_launch_info {
     uint32_t struct_size;   /* in: sizeof(rtmi_launch_info) */
-    uint32_t kernel;        /* 1 round-based, 2 queue-scheduled (rtmi_tuning::kernel, -DRTMI_EXPERIMENTAL builds only) */
+    uint32_t kernel;        /* 1: the round-based kernel (the only one since round 4) */
     uint32_t block_lanes;   /* lanes per workgroup */
     uint32_t grid_blocks;   /* persistent workgroups of one launch */
     uint32_t blocks_per_cu; /* resident workgroups per CU */

@@ -85,6 +85,8 @@ def lib():
     L.orc_pcg4d.argtypes = [vp, vp]
     L.orc_set_counter_rng.argtypes = [C.c_int]
     L.orc_get_counter_rng.restype = C.c_int
+    L.orc_set_pad_mode.argtypes = [C.c_int]
+    L.orc_get_pad_mode.restype = C.c_int
     L.orc_camera_setup.argtypes = [C.POINTER(CameraParams), C.POINTER(Camera)]
     L.orc_make_world_spheres.restype = C.c_uint32
     L.orc_make_world_spheres.argtypes = [C.POINTER(WorldDef), vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp,
@@ -122,6 +124,12 @@ def set_counter_rng(kind):
 
 def get_counter_rng():
     return int(lib().orc_get_counter_rng())
+
+
+def set_pad_mode(mode):
+    """Box pad of the instrumented walk: 0 farthest-centre class pad (rounds 1-3), 1 bounded by the segment's reach (the
+    product's), 2 none (not exact; measurements only)."""
+    lib().orc_set_pad_mode(int(mode))
 
 
 def _ptr(a):

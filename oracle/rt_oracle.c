@@ -472,6 +472,7 @@ typedef struct {
     const float* pad_classes;
     uint32_t n_classes;
     float pad_eps, pad_floor;
+    int pad_refine; /* pad_refine_pays(pad_classes): what pad mode 0 does */
 } scene_t;
 
 /* HittableObject_Collection::intersects, object.defs.cc:68-81: linear scan in insertion order,
@@ -521,12 +522,54 @@ static inline float sphere_candidate(const orc_object* s, const ray_t* r, float 
     return root;
 }
 
-static inline float ray_pad(const scene_t* sc, const ray_t* r) {
+/* Per-segment box pad.  Every sphere whose root the scan could accept must be reached, and the point of
+ * an accepted root lies within R + e(L) of the centre, e(L) = min(x / 2R, sqrt(x)), x = 64u (L^2 + R^2), L = |C - O|.
+ *   class pad (rounds 1-3): one number per radius class from the FARTHEST centre of the class: E0.
+ *   refined (round 4)     : an accepted root's point lies inside the class's centre box grown by G = rmax + E0, and before
+ *                           the far limit the segment starts with (the closest root among the peeled leaves), so
+ *                           L <= t_far |d| + G with t_far = min(limit, exit parameter from that box): E1 = e(L_max) <= E0.
+ *                           The floor follows the origin as well: 16u max(largest box coordinate, |O|_inf).
+ * The product refines on scenes much wider than their spheres -- E0 seen from the middle of a class's centre box above 5 % of
+ * the class's smallest radius (config 4: 0.44 on radius 0.2; S-RTOW: 0.002, where refining costs more than it culls) --
+ * and so does pad mode 0 here, from the same eight floats per class.  Modes: 0 auto (the product's default), 1 class pad,
+ * 2 refined, 3 no class pad at all (NOT exact; the lower bound of the walk's work, for measurements only).
+ * The kernel computes the same expression with v_rcp_f32 / v_sqrt_f32 where this file divides and calls sqrtf. */
+static int g_pad_mode = 0;
+void orc_set_pad_mode(int mode) { g_pad_mode = mode; }
+int orc_get_pad_mode(void) { return g_pad_mode; }
+
+/* rtmi::pad_refine_pays (csrc/rtmi_host.cpp), operation for operation */
+static int pad_refine_pays(const float* classes, uint32_t n_classes, float pad_eps) {
+    for (uint32_t c = 0; c < n_classes; ++c) {
+        const float* k = classes + 8 * c;
+        float far2 = 0.0f;
+        for (int i = 0; i < 3; ++i) {
+            const float m = 0.5f * k[i] + 0.5f * k[3 + i];
+            const float d0 = m - k[i], d1 = k[3 + i] - m;
+            far2 = far2 + fmaxf(d0 * d0, d1 * d1);
+        }
+        const float x = pad_eps * (far2 + k[7]);
+        const float e0 = fminf(x * k[6], sqrtf(x) * 1.000001f);
+        if (e0 * k[6] * 2.0f > 0.05f) return 1;
+    }
+    return 0;
+}
+
+static inline float ray_pad(const scene_t* sc, const ray_t* r, const float inv[3], const float oinv[3], float limit) {
+    const float o[3] = {r->o.x, r->o.y, r->o.z};
     float e = sc->pad_floor;
+    const int refine = g_pad_mode == 2 || (g_pad_mode == 0 && sc->pad_refine);
+    if (refine) {
+        const float oinf = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fabsf(o[2]));
+        e = fmaxf(e, 9.5367432e-7f * oinf); /* 16u |O|_inf */
+    }
+    if (g_pad_mode == 3) return e;
+    const float floor_ = e;
+    float dlen = 0.0f;
+    if (refine) dlen = sqrtf(vdot(r->d, r->d)) * 1.00001f;
     for (uint32_t c = 0; c < sc->n_classes; ++c) {
         const float* k = sc->pad_classes + 8 * c;
         float far2 = 0.0f;
-        const float o[3] = {r->o.x, r->o.y, r->o.z};
         for (int i = 0; i < 3; ++i) {
             const float d0 = o[i] - k[i];
             const float d1 = k[3 + i] - o[i];
@@ -534,7 +577,23 @@ static inline float ray_pad(const scene_t* sc, const ray_t* r) {
             far2 = far2 + m;
         }
         const float x = sc->pad_eps * (far2 + k[7]); /* k[7] = rmax^2 of the class; sqrt(R^2 + x) - R <= min(x / (2R), sqrt(x)) */
-        const float ec = fminf(x * k[6], sqrtf(x) * 1.000001f);
+        float ec = fminf(x * k[6], sqrtf(x) * 1.000001f);
+        if (refine) {
+            /* reach of the class around its centre box: rmax + E0, plus twice the floor for the rounding of the exit
+             * parameters below (each is off by at most ~3u (|plane| + |O|) |1/d|) */
+            const float g = (sqrtf(k[7]) * 1.000001f + ec) + 2.0f * floor_;
+            float t_exit = INFINITY;
+            for (int i = 0; i < 3; ++i) {
+                const float a = fmaf(k[i] - g, inv[i], oinv[i]);
+                const float b = fmaf(k[3 + i] + g, inv[i], oinv[i]);
+                t_exit = fminf(t_exit, fmaxf(a, b)); /* fmaxf / fminf drop a NaN operand (0 * inf): that axis does not bound */
+            }
+            const float t_far = fmaxf(fminf(limit, t_exit), 0.0f);
+            const float lmax = fmaf(t_far, dlen, g);
+            const float x1 = sc->pad_eps * (lmax * lmax + k[7]);
+            const float e1 = fminf(x1 * k[6], sqrtf(x1) * 1.000001f);
+            ec = fminf(ec, e1);
+        }
         e = fmaxf(e, ec);
     }
     return e;
@@ -544,12 +603,10 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
                           orc_counters* ctr) {
     const float inv[3] = {1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z};
     const float o[3] = {r->o.x, r->o.y, r->o.z};
-    const float pad = ray_pad(sc, r);
     float oinv[3], pinv[3], ainv[3];
     for (int i = 0; i < 3; ++i) {
         ainv[i] = fabsf(inv[i]);
         oinv[i] = -(o[i] * inv[i]);
-        pinv[i] = pad * ainv[i];
     }
     float best_t = INFINITY;
     uint32_t best = 0xffffffffu;
@@ -591,6 +648,9 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
             }
         }
     }
+    /* the pad of this segment's boxes, with the far limit the peeled leaves left */
+    const float pad = ray_pad(sc, r, inv, oinv, best_t);
+    for (int i = 0; i < 3; ++i) pinv[i] = pad * ainv[i];
     for (; !no_walk;) {
         if (cur & 0x80000000u) {
             const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
@@ -912,14 +972,35 @@ static int render_rect(const orc_camera* cam, const scene_t* sc, uint64_t seed, 
         jobs[t].next_row = &next_row;
         jobs[t].want_ctr = ctr != NULL;
     }
-    /* compute_color recurses maxdepth levels (core.cc:247, up to 65535): workers get a 1 GiB stack (reserved, touched on
-     * demand), also the single one -- the caller's own stack may be the 8 MiB default */
+    /* compute_color recurses maxdepth levels (core.cc:247, up to 65535): every worker -- also a single one, the caller's own
+     * stack may be the 8 MiB default -- gets a stack sized from the bounce limit (~1 KiB of frames per level measured; 4 KiB
+     * per level + 1 MiB reserved, touched on demand).  Rows are handed out by a shared counter, so the frame is complete
+     * with however many workers start; none starting is an error. */
+    if (!jobs || !th) {
+        free(jobs);
+        free(th);
+        return -2;
+    }
     pthread_attr_t attr;
     pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, (size_t)1 << 30);
-    for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], &attr, rect_worker, &jobs[t]);
-    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    size_t stack_bytes = ((size_t)cam->maxdepth * 4096u + ((size_t)1 << 20) + 65535u) & ~(size_t)65535u;
+    int started = 0;
+    for (int attempt = 0; attempt < 2 && started == 0; ++attempt) {
+        if (pthread_attr_setstacksize(&attr, stack_bytes) != 0) pthread_attr_setstacksize(&attr, (size_t)8 << 20);
+        for (int t = 0; t < nthreads; ++t) {
+            if (pthread_create(&th[started], &attr, rect_worker, &jobs[started]) != 0) break; /* (address space / cgroup limits) */
+            ++started;
+        }
+        if (started == 0) nthreads = 1; /* second attempt: one worker */
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
     pthread_attr_destroy(&attr);
+    if (started == 0) {
+        free(jobs);
+        free(th);
+        return -3;
+    }
+    nthreads = started;
     if (ctr) {
         for (int t = 0; t < nthreads; ++t) counters_add(ctr, &jobs[t].ctr);
     }
@@ -947,6 +1028,7 @@ int orc_render_rect_counter_bvh(const orc_camera* cam, const orc_object* objs, u
     sc.objs = objs; sc.n_objs = n_objs; sc.mats = mats; sc.n_mats = n_mats;
     sc.nodes = nodes; sc.n_nodes = n_nodes; sc.slots = slots; sc.n_slots = n_slots;
     sc.pad_classes = pad_classes; sc.n_classes = n_classes; sc.pad_eps = pad_eps; sc.pad_floor = pad_floor;
+    sc.pad_refine = pad_refine_pays(pad_classes, n_classes, pad_eps);
     if (n_slots == 0) return -1;
     return render_rect(cam, &sc, seed, x0, y0, x1, y1, rgb_out, rgba_out, ctr, nthreads);
 }

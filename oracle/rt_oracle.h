@@ -119,6 +119,10 @@ void orc_pcg4d(const uint32_t in[4], uint32_t out[4]);
 #endif
 void orc_set_counter_rng(int kind);
 int orc_get_counter_rng(void);
+/* box pad of the instrumented BVH walk: 0 = per class from its farthest centre (rounds 1-3), 1 = bounded by the reach of
+ * the segment (the product's, round 4), 2 = none (not exact: lower bound of the walk's work, measurements only) */
+void orc_set_pad_mode(int mode);
+int orc_get_pad_mode(void);
 void orc_counter_block(uint32_t blk, uint32_t sample, uint32_t pixel, const uint32_t key[2], uint32_t out[4]);
 
 /* --- host-side setup ------------------------------------------------------ */

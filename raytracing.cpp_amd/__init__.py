@@ -19,10 +19,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "librtmi.so")
 CSRC = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_host.cpp", "rtmi_device.hip", "rtmi_frame.hip")]
-# the queue-scheduled kernel of round 2 (slower than the round-based one on every measured workload): only
-# in libraries built with -DRTMI_EXPERIMENTAL (build_library(experimental=True) -> librtmi_exp.so, never the default)
-CSRC_EXPERIMENTAL = [os.path.join(_HERE, "csrc", "rtmi_wavefront.hip")]
-EXP_LIB_PATH = os.path.join(_HERE, "librtmi_exp.so")
 HEADERS = [os.path.join(_HERE, "csrc", "rtmi_internal.h"), os.path.join(_HERE, "csrc", "rtmi_kernel_common.h"),
            os.path.join(_ROOT, "include", "rtmi.h")]
 
@@ -40,17 +36,17 @@ RTMI_ERR_BAD_ARG, RTMI_ERR_HIP, RTMI_ERR_OOM, RTMI_ERR_UNSUPPORTED, RTMI_ERR_RCC
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
 
 
-def build_library(force=False, verbose=False, experimental=False):
+def build_library(force=False, verbose=False, out=None, defines=()):
     """Compile csrc/ for gfx950 with hipcc into librtmi.so (in-tree, so it travels to the GPU box).
-    experimental=True builds librtmi_exp.so instead: the same sources plus the queue-scheduled kernel."""
-    out = EXP_LIB_PATH if experimental else LIB_PATH
-    csrc = CSRC + (CSRC_EXPERIMENTAL if experimental else [])
+    `out` / `defines`: another file name and -D switches, for the A/B and diagnostic builds of tools/."""
+    out = out or LIB_PATH
+    csrc = CSRC
     srcs = csrc + HEADERS
     if (not force and os.path.exists(out)
             and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs)):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = ([hipcc] + HIPCC_FLAGS + (["-DRTMI_EXPERIMENTAL"] if experimental else [])
+    cmd = ([hipcc] + HIPCC_FLAGS + ["-D" + d for d in defines]
            + ["-I", os.path.join(_ROOT, "include"), "-o", out] + csrc + ["-ldl"])
     if verbose:
         print(" ".join(cmd))
@@ -81,11 +77,10 @@ class WorldDef(C.Structure):  # rtmi_world_def == reference src/ray.tracer.core.
 
 class Tuning(C.Structure):  # rtmi_tuning: scheduling knobs, 0 = default; none of them changes the image
     _fields_ = [("struct_size", C.c_uint32), ("block_lanes", C.c_uint32), ("blocks_per_cu", C.c_uint32),
-                ("wait_thresh", C.c_uint32), ("reserved0", C.c_uint32), ("chunk_samples", C.c_int32),
+                ("wait_thresh", C.c_uint32), ("pad_mode", C.c_uint32), ("chunk_samples", C.c_int32),
                 ("chain_mode", C.c_int32), ("reserved2", C.c_uint32), ("sample_buf_mb", C.c_uint32),
                 ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("kernel", C.c_uint32),
-                ("wf_block_lanes", C.c_uint32), ("wf_slots", C.c_uint32), ("wf_refill", C.c_uint32),
-                ("reserved", C.c_uint32 * 1)]
+                ("reserved3", C.c_uint32 * 3), ("lds_top_nodes", C.c_uint32)]
 
 
 class SceneOptions(C.Structure):
@@ -107,7 +102,7 @@ def make_tuning(**kw):
     """rtmi_tuning from keyword arguments (field names of include/rtmi.h); unknown names are an error."""
     t = Tuning()
     t.struct_size = C.sizeof(Tuning)
-    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved", "reserved0", "reserved2"}
+    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved2", "reserved3"}
     for k, v in kw.items():
         if k not in names:
             raise KeyError(f"unknown tuning knob {k!r}")
@@ -198,11 +193,6 @@ def lib():
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
-
-
-def experimental():
-    """True when the loaded library was built with -DRTMI_EXPERIMENTAL (carries the queue-scheduled kernel)."""
-    return b"experimental" in lib().rtmi_version()
 
 
 def _check(rc):

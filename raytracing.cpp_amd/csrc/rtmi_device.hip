@@ -430,20 +430,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             t.cur = P.root_ref;
             t.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
             PF_MARK(17);
-            float pad = P.pad_floor;
-            for (uint32_t c = 0; c < P.n_pad_classes; ++c) {
-                const float* k = P.pad_classes[c];
-                const float ax = fmaxf((o.x - k[0]) * (o.x - k[0]), (k[3] - o.x) * (k[3] - o.x));
-                const float ay = fmaxf((o.y - k[1]) * (o.y - k[1]), (k[4] - o.y) * (k[4] - o.y));
-                const float az = fmaxf((o.z - k[2]) * (o.z - k[2]), (k[5] - o.z) * (k[5] - o.z));
-                // sqrt(R^2 + x) - R <= min(x / (2R), sqrt(x)): the linear bound explodes for a ray that starts thousands of
-                // units away (a path inside the ground sphere), the square root does not
-                const float x = P.pad_eps * (((ax + ay) + az) + k[7]); // k[7]: rmax^2 of the class
-                pad = fmaxf(pad, fminf(x * k[6], __builtin_amdgcn_sqrtf(x) * 1.000001f));
-            }
             t.oinv = mk(-(o.x * t.inv.x), -(o.y * t.inv.y), -(o.z * t.inv.z));
-            t.pinv = mk(pad * __builtin_fabsf(t.inv.x), pad * __builtin_fabsf(t.inv.y), pad * __builtin_fabsf(t.inv.z));
-            PF_MARK(18);
             // Leaves that hang directly off the top of the tree -- the ground sphere, whose box is the whole scene; the
             // walls of a box made of huge spheres -- are tested here, by all the lanes that start a segment, and the
             // walk begins below them with the far limit already set: one node trip and one leaf trip less per leaf
@@ -461,6 +448,41 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                     test_leaf(ref);
                 }
             }
+            PF_MARK(18);
+            // The pad of this segment's boxes: every sphere whose root the reference's fp32 arithmetic could
+            // accept must be reached.  Per radius class, E0 = e(farthest centre of the class) bounds it for any ray from this
+            // origin; on scenes much wider than their spheres (pad_refine: the 316-unit grid of config 4, where E0 is 0.1-0.8
+            // units on spheres of radius 0.2) the segment's reach bounds it far better: an accepted root's point lies within
+            // G = rmax + E0 of a centre, hence inside the class's centre box grown by G, and before the far limit the peeled
+            // leaves left (the ground hit), so L <= t_far |d| + G and E1 = e(L_max) -- the same expression in the oracle's walk.
+            float pad = P.pad_floor;
+            if (P.pad_refine) pad = fmaxf(pad, 9.5367432e-7f * fmaxf(fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z))); // 16u |O|_inf
+            const float pad_floor_o = pad;
+            const float dlen = P.pad_refine ? __builtin_amdgcn_sqrtf(t.a) * 1.00001f : 0.0f;
+            for (uint32_t c = 0; c < P.n_pad_classes; ++c) {
+                const float* k = P.pad_classes[c];
+                const float ax = fmaxf((o.x - k[0]) * (o.x - k[0]), (k[3] - o.x) * (k[3] - o.x));
+                const float ay = fmaxf((o.y - k[1]) * (o.y - k[1]), (k[4] - o.y) * (k[4] - o.y));
+                const float az = fmaxf((o.z - k[2]) * (o.z - k[2]), (k[5] - o.z) * (k[5] - o.z));
+                // sqrt(R^2 + x) - R <= min(x / (2R), sqrt(x)): the linear bound explodes for a ray that starts thousands of
+                // units away (a path inside the ground sphere), the square root does not
+                const float x = P.pad_eps * (((ax + ay) + az) + k[7]); // k[7]: rmax^2 of the class
+                float ec = fminf(x * k[6], __builtin_amdgcn_sqrtf(x) * 1.000001f);
+                if (P.pad_refine) {
+                    // (twice the floor on top of the reach: the exit parameters below are off by at most ~3u (|plane| + |O|) |1/d|)
+                    const float g = __builtin_fmaf(2.0f, pad_floor_o, P.pad_rmax[c] + ec);
+                    const float ex = fmaxf(__builtin_fmaf(k[0] - g, t.inv.x, t.oinv.x), __builtin_fmaf(k[3] + g, t.inv.x, t.oinv.x));
+                    const float ey = fmaxf(__builtin_fmaf(k[1] - g, t.inv.y, t.oinv.y), __builtin_fmaf(k[4] + g, t.inv.y, t.oinv.y));
+                    const float ez = fmaxf(__builtin_fmaf(k[2] - g, t.inv.z, t.oinv.z), __builtin_fmaf(k[5] + g, t.inv.z, t.oinv.z));
+                    // (fmaxf / fminf drop a NaN operand -- 0 * inf on an axis-parallel ray: that axis does not bound the reach)
+                    const float t_far = fmaxf(fminf(fminf(ex, ey), fminf(ez, t.tbest)), 0.0f);
+                    const float lmax = __builtin_fmaf(t_far, dlen, g);
+                    const float x1 = P.pad_eps * (lmax * lmax + k[7]);
+                    ec = fminf(ec, fminf(x1 * k[6], __builtin_amdgcn_sqrtf(x1) * 1.000001f));
+                }
+                pad = fmaxf(pad, ec);
+            }
+            t.pinv = mk(pad * __builtin_fabsf(t.inv.x), pad * __builtin_fabsf(t.inv.y), pad * __builtin_fabsf(t.inv.z));
             PF_MARK(19);
         } else {
             t.cur = 0; // next sphere of the linear scan
@@ -1150,6 +1172,7 @@ struct rtmi_scene {
     uint32_t n_bands_timed = 0;
     uint32_t whole_pixel_fallbacks = 0; // launches that could not get their sample-record buffer
     bool top_down = false;
+    bool pad_refine = false; // box pad bounded by the segment's reach (rtmi_tuning::pad_mode; default: where it pays, Bvh::pad_refine)
     // launch geometry
     uint32_t block = 768, grid = 0, lds_bytes = 0, stack_depth = 0; // 2 x 768 lanes per CU = 6 waves per SIMD (<= 80 VGPRs)
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
@@ -1162,12 +1185,6 @@ struct rtmi_scene {
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     uint32_t pre_leaf_dev[4] = {}; // leaves peeled off the top of the tree, tested at segment set-up
     uint32_t n_pre_leaves = 0;
-    // queue-scheduled kernel (rtmi_wavefront.hip): its own launch geometry and LDS carve-up behind the staged scene
-    bool wf_enabled = false;
-    uint32_t wf_block = 1024, wf_grid = 0, wf_lds_bytes = 0, wf_slots = 0, wf_cap = 0, wf_refill = 24;
-    uint32_t wf_lds_stack = 0, wf_lds_fields = 0, wf_lds_rings = 0, wf_lds_ctrl = 0;
-    int wf_wpe = 4;
-    uint32_t* d_wf_error = nullptr;
     hipStream_t stream = nullptr; // private stream of the blocking entry point
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -1210,7 +1227,6 @@ void free_scene(rtmi_scene* s) {
     hipFree(s->d_rgba);
     hipFree(s->d_samples);
     hipFree(s->d_chain);
-    hipFree(s->d_wf_error);
     for (hipEvent_t e : s->ev_trace) hipEventDestroy(e);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
@@ -1260,6 +1276,8 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.n_pad_classes = s->bvh.n_pad_classes;
     P.pad_eps = s->bvh.pad_eps;
     P.pad_floor = s->bvh.pad_floor;
+    P.pad_refine = s->pad_refine ? 1u : 0u;
+    for (uint32_t c = 0; c < s->bvh.n_pad_classes; ++c) P.pad_rmax[c] = std::sqrt(s->bvh.pad_classes[c][7]) * 1.000001f;
     P.lds_spheres = s->lds_spheres;
     P.lds_aux = s->lds_aux;
     P.lds_mats = s->lds_mats;
@@ -1363,26 +1381,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         s->ev_trace.push_back(e);
     }
     HIP_TRY(hipEventRecord(s->ev_trace[2u * band], stream));
-#ifdef RTMI_EXPERIMENTAL
-    // queue-scheduled kernel: needs the sample records (any wave finishes any sample) and a tree to walk
-    const bool use_wf = s->wf_enabled && P.sample_buf != nullptr && s->accel == RTMI_ACCEL_BVH;
-#else
-    const bool use_wf = false;
-#endif
-    if (use_wf) {
-#ifdef RTMI_EXPERIMENTAL
-        P.lds_stack = s->wf_lds_stack;
-        P.wf_slots = s->wf_slots;
-        P.wf_cap_mask = s->wf_cap - 1u;
-        P.lds_wf_fields = s->wf_lds_fields;
-        P.lds_wf_rings = s->wf_lds_rings;
-        P.lds_wf_ctrl = s->wf_lds_ctrl;
-        P.wf_refill = s->wf_refill;
-        P.wf_error = s->d_wf_error;
-        const int rc = rtmi_wavefront_launch(P, s->collect_stats, s->big, s->wf_wpe, s->wf_grid, s->wf_block, s->wf_lds_bytes, stream);
-        if (rc != RTMI_OK) return rc;
-#endif
-    } else {
+    {
         KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big, mode);
         void* args[] = {&P};
         HIP_TRY(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream));
@@ -1397,7 +1396,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         A.out_rgb = d_rgb;
         A.out_rgba = d_rgba;
         const dim3 rgrid((A.n_pixels + 255u) / 256u);
-        if (mode == 4 && !use_wf) {
+        if (mode == 4) {
             A.chain_buf = P.chain_buf;
             A.mats = s->d_mats;
             A.n_mats = s->n_mats;
@@ -1420,19 +1419,6 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         HIP_TRY(hipEventRecord(s->ev1, stream));
         s->n_bands_timed = band + 1u;
         s->ev_valid = true;
-    }
-    return RTMI_OK;
-}
-
-// the queue-scheduled kernel bounds every wait; a watchdog that fired means the frame is incomplete
-int check_watchdog(rtmi_scene* s) {
-    if (!s->d_wf_error) return RTMI_OK;
-    uint32_t flag = 0;
-    HIP_TRY(hipMemcpy(&flag, s->d_wf_error, sizeof(flag), hipMemcpyDeviceToHost));
-    if (flag != 0u) {
-        (void)hipMemset(s->d_wf_error, 0, sizeof(flag));
-        set_error("rtmi: the queue-scheduled kernel aborted on its watchdog (a ring wait did not end); frame incomplete");
-        return RTMI_ERR_HIP;
     }
     return RTMI_OK;
 }
@@ -1771,6 +1757,11 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     if (tune.chunk_samples) s->chunk = tune.chunk_samples < 0 ? 0u : (uint32_t)tune.chunk_samples; // 0: split off
     if (tune.sample_buf_mb) s->sample_buf_cap_bytes = (size_t)tune.sample_buf_mb << 20;
     s->top_down = tune.top_down != 0;
+    if (tune.pad_mode > 2u) {
+        set_error("rtmi_scene_create: unknown rtmi_tuning::pad_mode");
+        return fail(RTMI_ERR_BAD_ARG);
+    }
+    s->pad_refine = tune.pad_mode == 0u ? s->bvh.pad_refine : tune.pad_mode == 2u;
     s->n_cus = (uint32_t)prop.multiProcessorCount;
     s->grid = s->n_cus * (uint32_t)per_cu;
     // the per-lane strips of attenuation runs grow with the bounce limit (8 bytes per bounce and lane): beyond 4 GiB the
@@ -1782,67 +1773,21 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         if (s->grid > fit) s->grid = (uint32_t)fit;
     }
 
-    // ---- queue-scheduled kernel: slot pool, rings and control words behind the staged scene and the stacks ------------
+    // (rtmi_tuning::kernel = 2 asked for round 2's queue-scheduled kernel: 0.52-0.85x on every BASELINE config, removed in round 4)
     if (tune.kernel > 2u) {
         set_error("rtmi_scene_create: unknown rtmi_tuning::kernel");
         return fail(RTMI_ERR_BAD_ARG);
     }
-#ifndef RTMI_EXPERIMENTAL
     if (tune.kernel == 2u) {
-        set_error("rtmi_scene_create: the queue-scheduled kernel (rtmi_tuning::kernel = 2) is an experiment that lost on every "
-                  "measured workload; it is only in libraries built with -DRTMI_EXPERIMENTAL");
+        set_error("rtmi_scene_create: the queue-scheduled kernel (rtmi_tuning::kernel = 2) lost on every measured workload "
+                  "and was removed in round 4 (git history keeps it)");
         return fail(RTMI_ERR_UNSUPPORTED);
     }
-#else
-    s->wf_enabled = s->accel == RTMI_ACCEL_BVH && n_objects > 0 && tune.kernel == 2u; // 0 / 1: round-based kernel
-    if (s->wf_enabled) {
-        if (tune.wf_block_lanes) s->wf_block = std::min(1024u, std::max(64u, (tune.wf_block_lanes / 64u) * 64u));
-        if (tune.wf_refill) s->wf_refill = std::min(64u, tune.wf_refill);
-        const uint32_t per_cu_target = s->wf_block <= 768u ? 2u : 1u;
-        s->wf_wpe = s->wf_block <= 768u ? 6 : 4;
-        const uint32_t limit = (160u * 1024u) / per_cu_target;
-        uint32_t base = 0;
-        if (!s->big) base = align16((uint32_t)s->bvh.nodes.size() * 64u + n_objects * 32u + n_materials * 16u);
-        s->wf_lds_stack = base;
-        base = align16(base + s->stack_depth * s->wf_block * (s->big ? 4u : 2u));
-        const uint32_t ctrl_bytes = (16u + (s->wf_block / 64u) * 16u) * 4u; // control words + a 64-byte rank table per wave
-        uint32_t ns = tune.wf_slots ? std::min(0xfffeu & ~63u, std::max(64u, (tune.wf_slots / 64u) * 64u)) : 2u * s->wf_block;
-        for (;; ns -= 64u) {
-            uint32_t cap = 64u;
-            while (cap < ns) cap <<= 1;
-            const uint64_t total = (uint64_t)base + (uint64_t)ns * kWfFields * 4u + 4ull * cap * 2u + ctrl_bytes;
-            if (total <= limit || ns <= 64u) {
-                s->wf_slots = ns;
-                s->wf_cap = cap;
-                s->wf_lds_fields = base;
-                s->wf_lds_rings = align16(base + ns * kWfFields * 4u);
-                s->wf_lds_ctrl = align16(s->wf_lds_rings + 4u * cap * 2u);
-                s->wf_lds_bytes = align16(s->wf_lds_ctrl + ctrl_bytes);
-                break;
-            }
-        }
-        if (s->wf_lds_bytes > 160u * 1024u) {
-            set_error("rtmi_scene_create: the queue-scheduled kernel does not fit the 160 KiB LDS of a CU with this scene");
-            return fail(RTMI_ERR_UNSUPPORTED);
-        }
-        int wf_per_cu = 0;
-        const int rc = rtmi_wavefront_occupancy(s->collect_stats, s->big, s->wf_wpe, s->wf_block, s->wf_lds_bytes, &wf_per_cu);
-        if (rc != RTMI_OK) return fail(rc);
-        if (wf_per_cu < 1) {
-            set_error("rtmi_scene_create: the queue-scheduled kernel cannot be resident with this scene");
-            return fail(RTMI_ERR_UNSUPPORTED);
-        }
-        if (tune.blocks_per_cu) wf_per_cu = std::max(1, std::min(wf_per_cu, (int)tune.blocks_per_cu));
-        s->wf_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)wf_per_cu;
-        HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_wf_error), 16));
-        HIP_TRY_S(hipMemset(s->d_wf_error, 0, 16));
-    }
-#endif
 
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_counter), 16));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 128 * sizeof(unsigned long long)));
     HIP_TRY_S(hipMemset(s->d_stats, 0, 128 * sizeof(unsigned long long)));
-    const size_t att_lanes = std::max<size_t>((size_t)s->grid * s->block, (size_t)s->wf_grid * s->wf_slots);
+    const size_t att_lanes = (size_t)s->grid * s->block;
     const size_t att_bytes = std::max<size_t>(16, (size_t)camera->maxdepth * att_lanes * 2u * sizeof(uint32_t));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->d_att), att_bytes));
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -1928,7 +1873,7 @@ static int render_rows_impl(rtmi_scene* s, uint32_t y0, uint32_t y1, uint64_t se
         HIP_TRY(hipMemcpyAsync(rgba8_out, s->d_rgba, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return check_watchdog(s);
+    return RTMI_OK;
 }
 
 extern "C" int rtmi_render_rows(rtmi_scene* s, uint32_t y0, uint32_t y1, uint64_t seed, float* rgb_linear_out,
@@ -1970,12 +1915,11 @@ extern "C" int rtmi_scene_get_launch_info(const rtmi_scene* s, rtmi_launch_info*
         set_error("rtmi_scene_get_launch_info: null argument or struct_size mismatch");
         return RTMI_ERR_BAD_ARG;
     }
-    const bool wf = s->wf_enabled && s->accel == RTMI_ACCEL_BVH;
-    out->kernel = wf ? 2u : 1u;
-    out->block_lanes = wf ? s->wf_block : s->block;
-    out->grid_blocks = wf ? s->wf_grid : s->grid;
+    out->kernel = 1u;
+    out->block_lanes = s->block;
+    out->grid_blocks = s->grid;
     out->blocks_per_cu = s->n_cus ? out->grid_blocks / s->n_cus : 0u;
-    out->lds_bytes = wf ? s->wf_lds_bytes : s->lds_bytes;
+    out->lds_bytes = s->lds_bytes;
     out->scene_in_lds = s->big ? 0u : 1u;
     out->stack_depth = s->stack_depth;
     out->whole_pixel_fallbacks = s->whole_pixel_fallbacks;
@@ -2025,7 +1969,7 @@ extern "C" int rtmi_scene_last_kernel_ms(rtmi_scene* s, float* ms_out) {
         total += ms;
     }
     *ms_out = total;
-    return check_watchdog(s);
+    return RTMI_OK;
 }
 
 #ifdef RTMI_PROF

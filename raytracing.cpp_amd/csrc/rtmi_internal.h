@@ -41,9 +41,11 @@ struct Bvh {
     uint32_t n_pad_classes = 0;
     float pad_eps = 0.0f;
     float pad_floor = 0.0f;
+    bool pad_refine = false; // pad_refine_pays(): bound the class pad by the segment's reach (scenes much wider than their spheres)
 };
 
 void set_error(const std::string& msg);
 void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& out);
+bool pad_refine_pays(const float (*classes)[8], uint32_t n_classes, float pad_eps);
 
 } // namespace rtmi

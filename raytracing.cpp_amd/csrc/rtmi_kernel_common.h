@@ -1,6 +1,5 @@
-// rtmi_kernel_common.h -- device-side pieces shared by the trace kernels (rtmi_device.hip: round-based kernel and the
-// linear scan; rtmi_wavefront.hip: queue-scheduled kernel): launch parameters, glm-semantics vec3, the counter RNG, the
-// wave-cooperative draw service and the reference's sphere arithmetic.  Reference lines are cited at each function.
+// rtmi_kernel_common.h -- device-side pieces of the trace kernel (rtmi_device.hip: BVH walk and linear scan): launch
+// parameters, glm-semantics vec3, the counter RNG, the wave-cooperative draw service and the reference's sphere arithmetic.  Reference lines are cited at each function.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -43,6 +42,8 @@ struct RtmiLaunch {
     float pad_classes[kMaxPadClasses][8];
     uint32_t n_pad_classes;
     float pad_eps, pad_floor;
+    uint32_t pad_refine;             // nonzero: the class pad is bounded by the segment's reach
+    float pad_rmax[kMaxPadClasses];  // sqrt(pad_classes[c][7]), rounded up
     // LDS carve-up (byte offsets)
     uint32_t lds_spheres, lds_aux, lds_mats, lds_nodes, lds_stack, stack_depth, lds_att, lds_pool;
     // image rows handled by this launch
@@ -67,21 +68,8 @@ struct RtmiLaunch {
     uint32_t att_bits, att_epw, att_words;
     uint32_t* chain_buf;
     unsigned long long* stats; // {samples, segments, sphere_tests, node_tests}
-    // queue-scheduled kernel (rtmi_wavefront.hip): path slots, rings and control words in LDS
-    uint32_t wf_slots;      // path slots per workgroup
-    uint32_t wf_cap_mask;   // ring capacity - 1 (power of two >= wf_slots)
-    uint32_t lds_wf_fields, lds_wf_rings, lds_wf_ctrl;
-    uint32_t wf_refill;     // a traversing wave takes new rays when this many of its lanes are idle
     FastDiv div_w;          // by the image width
-    uint32_t* wf_error;     // device word: nonzero if a watchdog fired
 };
-
-constexpr uint32_t kWfFields = 17; // dword arrays per path slot (rtmi_wavefront.hip)
-
-// host side of rtmi_wavefront.hip
-int rtmi_wavefront_occupancy(bool stats, bool big, int waves_per_eu, uint32_t block, uint32_t lds_bytes, int* per_cu);
-int rtmi_wavefront_launch(const RtmiLaunch& P, bool stats, bool big, int waves_per_eu, uint32_t grid, uint32_t block,
-                          uint32_t lds_bytes, hipStream_t stream);
 
 #define DEV static __device__ __forceinline__
 

@@ -155,11 +155,11 @@ def test_launch_info_reports_what_the_tuning_resolved_to(pkg, rtow, gpu):
     with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(force_hbm_scene=1, block_lanes=512)) as s:
         li2 = s.launch_info()
     assert li2["scene_in_lds"] == 0 and li2["block_lanes"] == 512 and li2["lds_bytes"] < li["lds_bytes"]
-    # the queue-scheduled kernel of round 2 is not in the shipped library (tests/test_experimental_gpu.py covers the
-    # -DRTMI_EXPERIMENTAL build): asking for it fails loudly instead of silently running something else
+    # the queue-scheduled kernel of round 2 (slower on every workload) was removed in round 4: asking for it fails loudly
+    # instead of silently running something else
     with pytest.raises(pkg.RtmiError) as e:
         pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(kernel=2))
-    assert e.value.code == pkg.RTMI_ERR_UNSUPPORTED and not pkg.experimental()
+    assert e.value.code == pkg.RTMI_ERR_UNSUPPORTED
     with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(blocks_per_cu=1)) as s:
         assert s.launch_info()["blocks_per_cu"] == 1
 
@@ -754,6 +754,39 @@ def test_regression_thumbnails(pkg, gpu, name):
     assert np.array_equal(rgba_to_rgb(rgba), read_png(os.path.join(GOLDEN, name + ".png")))
 
 
+def test_box_pad_rules_count_the_same_tests_as_the_oracle_walk(pkg, ob, gpu):
+    """The two pad rules of DESIGN.md 5.4 (rtmi_tuning::pad_mode 1 / 2; 0 = the library's choice: refined on the wide grid,
+    class pad on S-RTOW) on the GPU against the oracle's instrumented walk under the same rule: same frame, same segments,
+    box and sphere tests within 1e-3 (v_rcp_f32 / v_sqrt_f32 against true division and sqrtf)."""
+    worlds = []
+    objs, mats, kw = big_grid(120, seed=4)
+    worlds.append((objs, mats, dict(kw, image_width=96, samples_per_pixel=4, max_depth=30), 2))
+    objs, mats = pkg.make_world_spheres(4242)
+    worlds.append((objs, mats, dict(image_width=96, samples_per_pixel=4, max_depth=50), 1))
+    try:
+        for objs, mats, kw, auto_is in worlds:
+            cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+            counts = {}
+            for mode in (1, 2, 0):
+                for hbm in (0, 1):
+                    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, collect_stats=True,
+                                   tuning=dict(pad_mode=mode, force_hbm_scene=hbm)) as s:
+                        rgb, _ = s.render_rows(0, cam.img_height, 31)
+                        st = s.stats()
+                        bvh = s.bvh()
+                    ob.set_pad_mode(mode)
+                    want, _, c = ob.render_rect_counter(ocam, objs, mats, 31, 0, 0, ocam.img_width, ocam.img_height, nthreads=8,
+                                                        counters=True, bvh=bvh)
+                    _assert_frames_equal(rgb, want)
+                    assert st["segments"] == c["segments"]
+                    assert abs(st["node_tests"] - c["node_tests"]) <= 1e-3 * c["node_tests"], (mode, hbm)
+                    assert abs(st["sphere_tests"] - c["sphere_tests"]) <= 1e-3 * c["sphere_tests"], (mode, hbm)
+                    counts[mode, hbm] = c["node_tests"]
+            assert counts[0, 0] == counts[auto_is, 0] and counts[2, 0] <= counts[1, 0]
+    finally:
+        ob.set_pad_mode(0)
+
+
 def test_kernel_statistics_match_oracle_counters(pkg, ob, rtow, gpu):
     kw = dict(image_width=96, samples_per_pixel=8, max_depth=50)
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
@@ -946,7 +979,10 @@ def test_bvh_walk_equals_linear_scan_on_generated_worlds(pkg, gpu):
                       focus_distance=10.0, lookfrom=(far, 0.3 * far + 1.0, 0.5 * far), lookat=(0.0, 0.0, 0.0),
                       world_up=(0.0, 1.0, 0.0))
         cam = pkg.camera_setup(pkg.camera_params(**kw))
-        d = _bvh_equals_scan(pkg, cam, objs, mats, 77 + i, tunings=(dict(kernel=1), dict(force_hbm_scene=1)))
+        # (pad_mode 0: the library's choice -- the refined pad on the wide grids and the decades worlds, the class pad on the
+        # S-RTOW worlds; 2 / 1: the other rule forced on the same world)
+        d = _bvh_equals_scan(pkg, cam, objs, mats, 77 + i, tunings=(dict(kernel=1), dict(force_hbm_scene=1), dict(pad_mode=2),
+                                                                     dict(pad_mode=1, force_hbm_scene=1), dict(pad_mode=2, force_hbm_scene=1)))
         if d:
             bad[i] = d
     assert not bad, bad
@@ -981,7 +1017,8 @@ def test_bvh_walk_equals_linear_scan_on_grazing_rays(pkg, gpu):
                       focus_distance=dist, lookfrom=tuple(float(v) for v in O), lookat=tuple(float(v) for v in limb),
                       world_up=(0.0, 1.0, 0.0))
             cam = pkg.camera_setup(pkg.camera_params(**kw))
-            d = _bvh_equals_scan(pkg, cam, objs, mats, 5, tunings=(dict(kernel=1), dict(force_hbm_scene=1)))
+            d = _bvh_equals_scan(pkg, cam, objs, mats, 5, tunings=(dict(pad_mode=1), dict(pad_mode=1, force_hbm_scene=1), dict(pad_mode=2),
+                                                                   dict(pad_mode=2, force_hbm_scene=1)))
             assert d == 0, (target, R, L, d)
             checked += 1
     assert checked >= 15

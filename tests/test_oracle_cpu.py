@@ -387,6 +387,47 @@ def test_bvh_walk_with_leaves_peeled_off_the_top_equals_linear_scan(ob, pkg):
         assert c1["segments"] == c0["segments"] and c1["sphere_tests"] <= c0["sphere_tests"]
 
 
+def test_box_pad_rules_keep_the_walk_exact(ob, pkg):
+    """the class pad of rounds 1-3 (oracle pad mode 1) and the pad bounded by the segment's reach (mode 2) must
+    both give the linear scan's frame; mode 0 picks the refined rule on scenes much wider than their spheres (a jittered grid
+    over an R = 1e4 ground: the shape of config 4) and the class pad on S-RTOW, as the product does, and the refined rule visits
+    far fewer boxes there.  Cameras far from the scene and inside it; leaves of 2 and 4."""
+    from tests.scenes import big_grid, random_spheres
+    cases = []
+    objs, mats, kw = big_grid(40, seed=3)  # 40 units wide: the class pad is 4 % of the radius, refining does not pay
+    cases.append(("grid40", objs, mats, dict(kw, image_width=96, samples_per_pixel=3, max_depth=30), False))
+    objs, mats, kw = big_grid(120, seed=4)
+    cases.append(("grid120", objs, mats, dict(kw, image_width=64, samples_per_pixel=2, max_depth=30), True))
+    objs, mats, kw = big_grid(100, seed=5)
+    kw = dict(kw, image_width=64, samples_per_pixel=2, max_depth=20, lookfrom=(3.0, 0.8, 2.0), lookat=(0.0, 0.2, 0.0), vertical_fov=70.0,
+              focus_distance=3.0)
+    cases.append(("grid100-inside", objs, mats, kw, True))
+    objs, mats = random_spheres(400, seed=2, extent=60.0)
+    cases.append(("random-wide", objs, mats, dict(image_width=96, samples_per_pixel=3, max_depth=30, lookfrom=(70.0, 12.0, 20.0)), True))
+    objs, mats = ob.make_world_spheres(4242)
+    cases.append(("rtow", objs, mats, dict(image_width=96, samples_per_pixel=3, max_depth=50), False))
+    try:
+        for name, objs, mats, kw, wide in cases:
+            cam = ob.camera_setup(ob.camera_params(**kw))
+            W, H = cam.img_width, cam.img_height
+            ob.set_pad_mode(0)
+            lin, lin8 = ob.render_rect_counter(cam, objs, mats, 21, 0, 0, W, H, nthreads=8)
+            for leaf in (2, 4):
+                bvh = pkg.bvh_build(objs, leaf)
+                tests = {}
+                for mode in (1, 2, 0):
+                    ob.set_pad_mode(mode)
+                    got, got8, c = ob.render_rect_counter(cam, objs, mats, 21, 0, 0, W, H, nthreads=8, counters=True, bvh=bvh)
+                    assert got.tobytes() == lin.tobytes() and got8.tobytes() == lin8.tobytes(), (name, leaf, mode)
+                    tests[mode] = (c["node_tests"], c["sphere_tests"])
+                assert tests[0] == (tests[2] if wide else tests[1]), (name, leaf, tests)
+                assert tests[2][0] <= tests[1][0] and tests[2][1] <= tests[1][1], (name, leaf, tests)
+                if name == "grid120":
+                    assert tests[2][1] < 0.9 * tests[1][1], (name, leaf, tests)
+    finally:
+        ob.set_pad_mode(0)
+
+
 @pytest.mark.parametrize("name", ["thumb_config2", "thumb_config5"])
 def test_regression_thumbnails(ob, name):
     """tests/golden/thumb_*.png (make_thumbnails.py): the oracle's RGBA8 frames of configs 2 and 5 at thumbnail size."""
