@@ -124,7 +124,7 @@ typedef struct rtmi_tuning {
                                  * that lost on every measured workload, removed in round 4): RTMI_ERR_UNSUPPORTED */
     uint32_t reserved3[3];      /* (were wf_block_lanes / wf_slots / wf_refill, the geometry of that kernel) ignored */
     uint32_t lds_top_nodes;     /* HBM-resident trees: how many breadth-first nodes of the top of the tree each workgroup
-                                 * stages into LDS (0 = default: as many as fit next to the stacks; 1 = none) */
+                                 * stages into LDS (0 = default: as many as fit next to the stacks; n > 0: at most n - 1) */
 } rtmi_tuning;
 
 typedef struct rtmi_scene_options {
@@ -216,7 +216,13 @@ typedef struct rtmi_launch_info {
     uint32_t whole_pixel_fallbacks; /* launches so far whose sample-record buffer (16 B per sample of the call, capped by
                              * rtmi_tuning::sample_buf_mb) could not be allocated: they ran with whole-pixel work items --
                              * the same image, but a longer tail at the end of the launch */
-    uint32_t packed_chains; /* 0: run-length encoded attenuation chains; else the words per sample of the packed form */
+    uint32_t packed_chains; /* 0: run-length encoded attenuation chains; else the words per sample of the packed form the scene
+                             * is eligible for (what a launch does when its chain slots can be allocated) */
+    /* ---- added in 0.4 (a caller built against the 40-byte struct of 0.3 passes struct_size = 40 and gets the fields above) ---- */
+    uint32_t packed_chain_fallbacks; /* launches so far of a scene eligible for packed chains that ran with run-length encoded
+                             * chains instead (their chain slots could not be allocated or passed the buffer cap): same image */
+    uint32_t lds_top_nodes; /* HBM-resident trees: breadth-first nodes of the top of the tree staged into LDS by every workgroup */
+    uint32_t pad_mode;      /* what rtmi_tuning::pad_mode resolved to: 1 class pad, 2 bounded by the segment's reach (0: no BVH) */
 } rtmi_launch_info;
 int rtmi_scene_get_launch_info(const rtmi_scene* scene, rtmi_launch_info* out);
 /* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), rmax^2}. */

@@ -91,7 +91,7 @@ class SceneOptions(C.Structure):
 class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("struct_size", "kernel", "block_lanes", "grid_blocks", "blocks_per_cu",
                                           "lds_bytes", "scene_in_lds", "stack_depth", "whole_pixel_fallbacks",
-                                          "packed_chains")]
+                                          "packed_chains", "packed_chain_fallbacks", "lds_top_nodes", "pad_mode")]
 
 
 class FrameTiming(C.Structure):

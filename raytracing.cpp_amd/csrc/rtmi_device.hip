@@ -168,7 +168,11 @@ DEV void walk_nodes_lds(Trav& t, uint32_t nbase, uint32_t stride, int floor, int
 // 32-bit stack entries.  v_fma_mix_f32 takes the fp16 half extents as they are (exact conversion inside the FMA: the same
 // value as v_cvt_f32_f16 + v_fma_f32, six instructions less per trip).
 //   v66-v69 = c0x c0y c0z c1x   v70-v73 = c1y c1z h0x|h0y h0z|h1x   v74-v77 = h1y|h1z ch0 ch1 -
-DEV void walk_nodes_hbm(Trav& t, const uint4* nodes, uint32_t stride, int floor, int& n_leaf, int& n_node) {
+// The first `ktop` nodes of the breadth-first numbering -- the levels every walk passes through -- are staged into LDS by every
+// workgroup (the same 48-byte records at LDS address nbase + 48 * cur): a trip reads them with three ds_read_b128 and only
+// the lanes below that top go to memory.  A node read through the vector-memory path costs the CU's address unit 16 cycles per
+// 16-byte instruction whatever the hit rate (rocprofv3, round 3: 73 % of its cycles on config 4).
+DEV void walk_nodes_hbm(Trav& t, const uint4* nodes, uint32_t nbase, uint32_t ktop, uint32_t stride, int floor, int& n_leaf, int& n_node) {
     int tmp;
     uint64_t m_node, m_leaf, saved, hit0, hit1;
     float x, y, z, tn0;
@@ -185,22 +189,34 @@ DEV void walk_nodes_hbm(Trav& t, const uint4* nodes, uint32_t stride, int floor,
         "s_cbranch_scc1 L_exit_%=\n\t"
         "s_and_saveexec_b64 %[saved], %[mnode]\n\t"
         "v_mul_u32_u24_e32 %[x], 48, %[cur]\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[ktop], %[cur]\n\t"     // this lane's node is in the staged top
+        "s_and_saveexec_b64 %[hit0], vcc\n\t"
+        "s_cbranch_execz L_nolds_%=\n\t"
+        "v_add_u32_e32 %[y], %[nbase], %[x]\n\t"
+        "ds_read_b128 v[66:69], %[y]\n\t"
+        "ds_read_b128 v[70:73], %[y] offset:16\n\t"
+        "ds_read_b128 v[74:77], %[y] offset:32\n\t"
+        "L_nolds_%=:\n\t"
+        "s_andn2_b64 exec, %[hit0], vcc\n\t"
+        "s_cbranch_execz L_nomem_%=\n\t"
         "global_load_dwordx4 v[66:69], %[x], %[nodes]\n\t"
         "global_load_dwordx4 v[70:73], %[x], %[nodes] offset:16\n\t"
         "global_load_dwordx4 v[74:77], %[x], %[nodes] offset:32\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
+        "L_nomem_%=:\n\t"
+        "s_mov_b64 exec, %[hit0]\n\t"
+        "s_waitcnt vmcnt(2) lgkmcnt(2)\n\t"
         "v_fma_f32 v66, v66, %[ix], %[ox]\n\t"      // tc0x
         "v_fma_f32 v67, v67, %[iy], %[oy]\n\t"      // tc0y
         "v_fma_f32 v68, v68, %[iz], %[oz]\n\t"      // tc0z
         "v_fma_f32 v69, v69, %[ix], %[ox]\n\t"      // tc1x
-        "s_waitcnt vmcnt(1)\n\t"
+        "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t"
         "v_fma_f32 v70, v70, %[iy], %[oy]\n\t"      // tc1y
         "v_fma_f32 v71, v71, %[iz], %[oz]\n\t"      // tc1z
         "v_fma_mix_f32 v78, v72, |%[ix]|, %[px] op_sel_hi:[1,0,0]\n\t"                  // th0x: the pad rides in the FMA of the half extent
         "v_fma_mix_f32 v72, v72, |%[iy]|, %[py] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th0y
         "v_fma_mix_f32 v79, v73, |%[iz]|, %[pz] op_sel_hi:[1,0,0]\n\t"                  // th0z
         "v_fma_mix_f32 v73, v73, |%[ix]|, %[px] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th1x
-        "s_waitcnt vmcnt(0)\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
         "v_fma_mix_f32 v77, v74, |%[iy]|, %[py] op_sel_hi:[1,0,0]\n\t"                  // th1y
         "v_fma_mix_f32 v74, v74, |%[iz]|, %[pz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th1z
         "v_sub_f32_e32 %[x], v66, v78\n\t"          // box 0, near: max(x, y, max(z, 1e-4))
@@ -249,7 +265,7 @@ DEV void walk_nodes_hbm(Trav& t, const uint4* nodes, uint32_t stride, int floor,
           [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [tn0] "=&v"(tn0)
         : [ix] "v"(t.inv.x), [iy] "v"(t.inv.y), [iz] "v"(t.inv.z), [ox] "v"(t.oinv.x), [oy] "v"(t.oinv.y),
           [oz] "v"(t.oinv.z), [px] "v"(t.pinv.x), [py] "v"(t.pinv.y), [pz] "v"(t.pinv.z), [tbest] "v"(t.tbest),
-          [stride] "v"(stride), [nodes] "s"(nodes), [floor] "s"(floor)
+          [stride] "v"(stride), [nodes] "s"(nodes), [nbase] "s"(nbase), [ktop] "s"(ktop), [floor] "s"(floor)
         : "vcc", "scc", "memory", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
           "v78", "v79");
 }
@@ -294,12 +310,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
     const uint4* lds_mats;
     const uint4* lds_nodes;
     if (BIG) {
-        // (staging the top levels of the tree into LDS was measured at 100k spheres: 17.2 ms with 147 nodes staged,
-        // 17.0 ms with none -- they are L2 hits anyway -- and a pointer that may be LDS or global costs flat_* loads)
+        // the scene stays in memory; the first lds_top_nodes nodes of the breadth-first numbering (48-byte records) start the
+        // dynamic LDS segment and the node step reads them from there (walk_nodes_hbm)
         lds_spheres = P.spheres;
         lds_aux = P.aux;
         lds_mats = P.mats;
         lds_nodes = P.nodes;
+        if (ACCEL == RTMI_ACCEL_BVH && P.lds_top_nodes != 0u) {
+            uint4* w_nodes = reinterpret_cast<uint4*>(lds_raw);
+            for (uint32_t i = threadIdx.x; i < 3u * P.lds_top_nodes; i += blockDim.x) w_nodes[i] = P.nodes[i];
+            __syncthreads();
+        }
     } else {
         // ---- stage the scene into LDS: coalesced 16-byte loads, one pass per array -------------------------
         uint4* w_spheres = reinterpret_cast<uint4*>(lds_raw + P.lds_spheres);
@@ -619,7 +640,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
 #if RTMI_ASM_WALK && !(defined(RTMI_PROF) && RTMI_PROF == 1)
                 if (!STATS && (!BIG || RTMI_WPE_BIG <= 6)) {
                     int n_leaf, n_node;
-                    if (BIG) walk_nodes_hbm(t, lds_nodes, sp_stride, trav_floor, n_leaf, n_node);
+                    if (BIG) walk_nodes_hbm(t, lds_nodes, lds0, P.lds_top_nodes, sp_stride, trav_floor, n_leaf, n_node);
                     else walk_nodes_lds(t, lds0, sp_stride, trav_floor, n_leaf, n_node); // nodes start the dynamic LDS segment
                     if (n_leaf + n_node <= trav_floor) break;
                     if ((int32_t)t.cur < -1) { // the leaf step won the vote
@@ -653,9 +674,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                     PF_MARK(21);
                 } else if (at_node) {
                     NodeFields nd;
-                    if (BIG) { // 48-byte records read through L1 / L2 / Infinity Cache (config 4)
-                        const uint4* np = lds_nodes + 3u * t.cur;
-                        const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
+                    if (BIG) { // 48-byte records: the staged top of the tree from LDS, the rest through L1 / L2 / Infinity Cache (config 4)
+                        uint4 n0, n1, n2;
+                        if (t.cur < P.lds_top_nodes) {
+                            typedef __attribute__((address_space(3))) uint32_t lds_u32;
+                            const lds_u32* np = (const lds_u32*)(uintptr_t)(lds0 + 48u * t.cur);
+                            n0 = make_uint4(np[0], np[1], np[2], np[3]);
+                            n1 = make_uint4(np[4], np[5], np[6], np[7]);
+                            n2 = make_uint4(np[8], np[9], np[10], np[11]);
+                        } else {
+                            const uint4* np = lds_nodes + 3u * t.cur;
+                            n0 = np[0]; n1 = np[1]; n2 = np[2];
+                        }
                         nd = unpack_node48(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z);
                     } else { // 64-byte records in LDS
                         const uint4* np = lds_nodes + 4u * t.cur;
@@ -1171,6 +1201,7 @@ struct rtmi_scene {
     std::vector<hipEvent_t> ev_trace; // [2 * band]: before / after that band's trace kernel
     uint32_t n_bands_timed = 0;
     uint32_t whole_pixel_fallbacks = 0; // launches that could not get their sample-record buffer
+    uint32_t packed_chain_fallbacks = 0; // launches of a packed-chain scene that ran with run-length encoded chains
     bool top_down = false;
     bool pad_refine = false; // box pad bounded by the segment's reach (rtmi_tuning::pad_mode; default: where it pays, Bvh::pad_refine)
     // launch geometry
@@ -1181,6 +1212,7 @@ struct rtmi_scene {
     uint32_t wait_thresh = 52;
 
     uint32_t lds_att = 0, lds_pool = 0;
+    uint32_t lds_top_nodes = 0; // HBM-resident trees: breadth-first nodes staged into LDS (48-byte records at the start of the segment)
     uint32_t n_cus = 0;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     uint32_t pre_leaf_dev[4] = {}; // leaves peeled off the top of the tree, tested at segment set-up
@@ -1283,6 +1315,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.lds_mats = s->lds_mats;
     P.lds_nodes = s->lds_nodes;
     P.lds_stack = s->lds_stack;
+    P.lds_top_nodes = s->lds_top_nodes;
     P.lds_att = s->lds_att;
     P.lds_pool = s->lds_pool;
     P.stack_depth = s->stack_depth;
@@ -1334,8 +1367,9 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     }
     // packed chains travel with the sample records: att_words words per sample next to the 16-byte record
     int mode = P.sample_buf ? 0 : 3;
-    if (P.sample_buf && s->packed_ok &&
-        (sample_floats * (sizeof(float4) + (size_t)s->att_words * 4u)) <= s->sample_buf_cap_bytes) {
+    const bool chain_slots_fit = (sample_floats * (sizeof(float4) + (size_t)s->att_words * 4u)) <= s->sample_buf_cap_bytes;
+    if (P.sample_buf && s->packed_ok && !chain_slots_fit) s->packed_chain_fallbacks++;
+    if (P.sample_buf && s->packed_ok && chain_slots_fit) {
         if (sample_floats > s->chain_capacity) {
             hipFree(s->d_chain);
             s->d_chain = nullptr;
@@ -1344,6 +1378,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
                 s->chain_capacity = sample_floats;
             } else {
                 (void)hipGetLastError(); // no room: the run-length encoded chains of mode 0 instead
+                s->packed_chain_fallbacks++; // (reported by rtmi_scene_get_launch_info: same image, chains multiplied at path end)
             }
         }
         if (s->d_chain) {
@@ -1614,6 +1649,16 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         s->lds_mats = off;
         off += n_materials * 16u;
         off = align16(off);
+    } else if (s->accel == RTMI_ACCEL_BVH && !s->bvh.nodes.empty()) {
+        // the top of the tree in what the stacks leave of the 80 KiB (two workgroups per CU): the 100k-sphere tree of config 4
+        // has 18 levels = 61 KB of 32-bit stack entries for 768 lanes, which leaves 384 of its 32 902 nodes -- its first eight
+        // levels and half of the ninth (rtmi_tuning::lds_top_nodes caps it: n > 0 = at most n - 1 nodes)
+        const uint64_t fixed = (uint64_t)s->stack_depth * s->block * 4u + (uint64_t)(s->block / 64u) * 80u + 64u;
+        uint64_t k = fixed < 80u * 1024u ? (80u * 1024u - fixed) / 48u : 0u;
+        k = std::min<uint64_t>(k, s->bvh.nodes.size());
+        if (tune.lds_top_nodes) k = std::min<uint64_t>(k, tune.lds_top_nodes - 1u);
+        s->lds_top_nodes = (uint32_t)k;
+        off = align16((uint32_t)k * 48u);
     }
     s->lds_stack = off;
     off += s->stack_depth * s->block * (s->big ? 4u : 2u);
@@ -1911,19 +1956,28 @@ extern "C" int rtmi_scene_get_accel(const rtmi_scene* s, uint32_t* accel_out) {
 }
 
 extern "C" int rtmi_scene_get_launch_info(const rtmi_scene* s, rtmi_launch_info* out) {
-    if (!s || !out || out->struct_size != sizeof(rtmi_launch_info)) {
-        set_error("rtmi_scene_get_launch_info: null argument or struct_size mismatch");
+    // (the struct grows at its end: a caller built against an older header passes its own, smaller struct_size and gets the
+    // fields it knows -- 40 bytes in 0.3)
+    constexpr uint32_t kSizeV03 = 40u;
+    if (!s || !out || out->struct_size < kSizeV03) {
+        set_error("rtmi_scene_get_launch_info: null argument or struct_size below the 40 bytes of version 0.3");
         return RTMI_ERR_BAD_ARG;
     }
-    out->kernel = 1u;
-    out->block_lanes = s->block;
-    out->grid_blocks = s->grid;
-    out->blocks_per_cu = s->n_cus ? out->grid_blocks / s->n_cus : 0u;
-    out->lds_bytes = s->lds_bytes;
-    out->scene_in_lds = s->big ? 0u : 1u;
-    out->stack_depth = s->stack_depth;
-    out->whole_pixel_fallbacks = s->whole_pixel_fallbacks;
-    out->packed_chains = s->packed_ok ? s->att_words : 0u;
+    rtmi_launch_info v{};
+    v.struct_size = out->struct_size;
+    v.kernel = 1u;
+    v.block_lanes = s->block;
+    v.grid_blocks = s->grid;
+    v.blocks_per_cu = s->n_cus ? v.grid_blocks / s->n_cus : 0u;
+    v.lds_bytes = s->lds_bytes;
+    v.scene_in_lds = s->big ? 0u : 1u;
+    v.stack_depth = s->stack_depth;
+    v.whole_pixel_fallbacks = s->whole_pixel_fallbacks;
+    v.packed_chains = s->packed_ok ? s->att_words : 0u;
+    v.packed_chain_fallbacks = s->packed_chain_fallbacks;
+    v.lds_top_nodes = s->lds_top_nodes;
+    v.pad_mode = s->accel == RTMI_ACCEL_BVH ? (s->pad_refine ? 2u : 1u) : 0u;
+    std::memcpy(out, &v, std::min<size_t>(out->struct_size, sizeof(v)));
     return RTMI_OK;
 }
 

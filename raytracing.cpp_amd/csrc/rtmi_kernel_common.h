@@ -46,6 +46,7 @@ struct RtmiLaunch {
     float pad_rmax[kMaxPadClasses];  // sqrt(pad_classes[c][7]), rounded up
     // LDS carve-up (byte offsets)
     uint32_t lds_spheres, lds_aux, lds_mats, lds_nodes, lds_stack, stack_depth, lds_att, lds_pool;
+    uint32_t lds_top_nodes;   // HBM-resident trees: this many breadth-first nodes (48-byte records) start the LDS segment
     // image rows handled by this launch
     uint32_t y_first, block_rows, block_stride, n_local_rows;
     uint32_t tiles_x, tiles_y, n_work; // work index space = tiles * 64

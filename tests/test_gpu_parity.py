@@ -162,6 +162,22 @@ def test_launch_info_reports_what_the_tuning_resolved_to(pkg, rtow, gpu):
     assert e.value.code == pkg.RTMI_ERR_UNSUPPORTED
     with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(blocks_per_cu=1)) as s:
         assert s.launch_info()["blocks_per_cu"] == 1
+        # a caller built against the 40-byte rtmi_launch_info of version 0.3 gets the fields it knows and nothing beyond them
+        import ctypes as C
+        old = (C.c_uint32 * 13)(*([40] + [0xdeadbeef] * 12))
+        assert pkg.lib().rtmi_scene_get_launch_info(s._h, C.cast(old, C.POINTER(pkg.LaunchInfo))) == 0
+        assert old[1] == 1 and old[4] == 1 and list(old[10:]) == [0xdeadbeef] * 3
+        old[0] = 36
+        assert pkg.lib().rtmi_scene_get_launch_info(s._h, C.cast(old, C.POINTER(pkg.LaunchInfo))) == pkg.RTMI_ERR_BAD_ARG
+    # HBM-resident trees: the top of the tree is staged into LDS (as many breadth-first nodes as fit next to the stacks; here the
+    # whole 288-node tree), rtmi_tuning::lds_top_nodes caps it (n > 0: at most n - 1 nodes)
+    for cap, want_top in ((0, None), (1, 0), (41, 40)):
+        with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(force_hbm_scene=1, lds_top_nodes=cap)) as s:
+            li3 = s.launch_info()
+            assert li3["scene_in_lds"] == 0 and li3["lds_top_nodes"] == (len(s.bvh()["nodes"]) if want_top is None else want_top)
+            assert li3["pad_mode"] == 1
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BRUTE) as s:
+        assert s.launch_info()["pad_mode"] == 0 and s.launch_info()["lds_top_nodes"] == 0
 
 
 def test_scheduling_knobs_do_not_change_the_image(pkg, ob, rtow, gpu):
@@ -196,6 +212,7 @@ def test_packed_and_run_length_attenuation_chains(pkg, ob, rtow, gpu):
                 assert (s.launch_info()["packed_chains"] > 0) == packed
                 rgb, rgba = s.render_rows(0, ccam.img_height, int(g["seed"]))
                 part, _ = s.render_rows(7, 19, int(g["seed"]))
+                assert s.launch_info()["packed_chain_fallbacks"] == 0  # what was launched is what the scene is eligible for
             _assert_frames_equal(rgb, g["rgb"])
             assert np.array_equal(rgba, g["rgba"])
             _assert_frames_equal(part, g["rgb"][7:19])
@@ -981,8 +998,11 @@ def test_bvh_walk_equals_linear_scan_on_generated_worlds(pkg, gpu):
         cam = pkg.camera_setup(pkg.camera_params(**kw))
         # (pad_mode 0: the library's choice -- the refined pad on the wide grids and the decades worlds, the class pad on the
         # S-RTOW worlds; 2 / 1: the other rule forced on the same world)
+        # (lds_top_nodes: the staged top of an HBM-resident tree -- all of it that fits by default, none, the first 40 nodes:
+        # waves whose lanes read nodes from LDS and from memory in the same trip)
         d = _bvh_equals_scan(pkg, cam, objs, mats, 77 + i, tunings=(dict(kernel=1), dict(force_hbm_scene=1), dict(pad_mode=2),
-                                                                     dict(pad_mode=1, force_hbm_scene=1), dict(pad_mode=2, force_hbm_scene=1)))
+                                                                     dict(pad_mode=1, force_hbm_scene=1, lds_top_nodes=1),
+                                                                     dict(pad_mode=2, force_hbm_scene=1, lds_top_nodes=41)))
         if d:
             bad[i] = d
     assert not bad, bad
