@@ -116,7 +116,9 @@ typedef struct rtmi_tuning {
     int32_t chain_mode;         /* attenuation chains: 0 = auto (packed strings of material handles in LDS, multiplied by the
                                  * resolve pass, when they fit next to the scene; else run-length encoded runs with per-lane
                                  * strips in HBM, multiplied at path end), 1 = always the run-length encoded form */
-    uint32_t reserved2;         /* (was defer_cap) ignored */
+    uint32_t bvh_passes;        /* reinsertion passes over the BVH after the top-down SAH build: 0 = default (2; none above 8192 objects), n > 0 = n - 1
+                                 * (1 = the plain top-down tree of rounds 1-3); any tree gives the same image.
+                                 * (This slot was defer_cap until round 2 and ignored in round 3.) */
     uint32_t sample_buf_mb;     /* cap on the sample-record buffer in MiB (default 24576); larger calls run in row bands */
     uint32_t force_hbm_scene;   /* nonzero: leave the scene in HBM even when it fits LDS (the config-4 path) */
     uint32_t top_down;          /* nonzero: hand out tiles top row first instead of bottom row first */
@@ -234,6 +236,10 @@ int rtmi_scene_get_bvh(const rtmi_scene* scene, rtmi_bvh_node* nodes_out, uint32
 int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, rtmi_bvh_node* nodes_out,
                    uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref, uint32_t* depth,
                    float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor);
+/* Same with the number of reinsertion passes chosen as in rtmi_tuning::bvh_passes (0 = default, n > 0 = n - 1). */
+int rtmi_bvh_build_passes(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, uint32_t bvh_passes,
+                          rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref,
+                          uint32_t* depth, float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor);
 /* duration in milliseconds of the most recent TRACE kernel of this scene (the ordered resolve pass that follows it is
  * not included), from HIP events recorded on the launch stream; blocks until that launch has finished.  Used by
  * bench.py for the roofline line. */

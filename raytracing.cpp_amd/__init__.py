@@ -78,7 +78,7 @@ class WorldDef(C.Structure):  # rtmi_world_def == reference src/ray.tracer.core.
 class Tuning(C.Structure):  # rtmi_tuning: scheduling knobs, 0 = default; none of them changes the image
     _fields_ = [("struct_size", C.c_uint32), ("block_lanes", C.c_uint32), ("blocks_per_cu", C.c_uint32),
                 ("wait_thresh", C.c_uint32), ("pad_mode", C.c_uint32), ("chunk_samples", C.c_int32),
-                ("chain_mode", C.c_int32), ("reserved2", C.c_uint32), ("sample_buf_mb", C.c_uint32),
+                ("chain_mode", C.c_int32), ("bvh_passes", C.c_uint32), ("sample_buf_mb", C.c_uint32),
                 ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("kernel", C.c_uint32),
                 ("reserved3", C.c_uint32 * 3), ("lds_top_nodes", C.c_uint32)]
 
@@ -102,7 +102,7 @@ def make_tuning(**kw):
     """rtmi_tuning from keyword arguments (field names of include/rtmi.h); unknown names are an error."""
     t = Tuning()
     t.struct_size = C.sizeof(Tuning)
-    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved2", "reserved3"}
+    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved3"}
     for k, v in kw.items():
         if k not in names:
             raise KeyError(f"unknown tuning knob {k!r}")
@@ -136,7 +136,7 @@ assert OBJECT_DTYPE.itemsize == 24 and MATERIAL_DTYPE.itemsize == 20 and BVH_NOD
 EXPORTS = ("rtmi_camera_setup", "rtmi_make_world_spheres", "rtmi_scene_create", "rtmi_scene_destroy",
            "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_last_error", "rtmi_version",
            "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_launch_info", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
-           "rtmi_bvh_build", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
+           "rtmi_bvh_build", "rtmi_bvh_build_passes", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
            "rtmi_frame_render_device", "rtmi_frame_get_timing", "rtmi_frame_rccl_ranks", "rtmi_frame_get_scene")
 
 _lib = None
@@ -178,6 +178,8 @@ def lib():
     L.rtmi_scene_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     u32p, f32p = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
     L.rtmi_bvh_build.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u32p, vp, u32p, u32p, vp, u32p, f32p, f32p]
+    if hasattr(L, "rtmi_bvh_build_passes"):  # (absent from older builds that tools/ A/B against the current one)
+        L.rtmi_bvh_build_passes.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p, vp, u32p, u32p, vp, u32p, f32p, f32p]
     L.rtmi_frame_create.argtypes = [C.POINTER(Camera), vp, C.c_uint32, vp, C.c_uint32, C.POINTER(SceneOptions),
                                     C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.rtmi_frame_destroy.argtypes = [vp]
@@ -396,8 +398,8 @@ class Frame:
         return v.value
 
 
-def bvh_build(objs, leaf_size=0):
-    """rtmi_bvh_build: the host-side BVH of a scene (no device needed)."""
+def bvh_build(objs, leaf_size=0, bvh_passes=0):
+    """rtmi_bvh_build_passes: the host-side BVH of a scene (no device needed); bvh_passes as rtmi_tuning::bvh_passes."""
     objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
     n = len(objs)
     nodes = np.zeros(max(n, 1), BVH_NODE_DTYPE)
@@ -405,8 +407,8 @@ def bvh_build(objs, leaf_size=0):
     pc = np.zeros((4, 8), np.float32)
     nn, root, depth, nc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
     eps, floor = C.c_float(0), C.c_float(0)
-    _check(lib().rtmi_bvh_build(_ptr(objs), n, leaf_size, _ptr(nodes), C.byref(nn), _ptr(slots), C.byref(root),
-                                C.byref(depth), _ptr(pc), C.byref(nc), C.byref(eps), C.byref(floor)))
+    _check(lib().rtmi_bvh_build_passes(_ptr(objs), n, leaf_size, bvh_passes, _ptr(nodes), C.byref(nn), _ptr(slots),
+                                       C.byref(root), C.byref(depth), _ptr(pc), C.byref(nc), C.byref(eps), C.byref(floor)))
     return dict(nodes=nodes[:nn.value].copy(), slots=slots[:n].copy(), pad_classes=pc[:nc.value].copy(),
                 pad_eps=eps.value, pad_floor=floor.value, root_ref=root.value, depth=depth.value)
 

@@ -1583,7 +1583,8 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         // More than 8192 spheres cannot be in LDS, which is known before the build; scenes between ~640 and 8192 spheres, whose
         // residency depends on the tree, keep 2.
         const uint32_t leaf_default = n_objects > 0x2000u ? 4u : 2u;
-        build_bvh(objects, n_objects, opt.leaf_size ? opt.leaf_size : leaf_default, s->bvh);
+        build_bvh(objects, n_objects, opt.leaf_size ? opt.leaf_size : leaf_default,
+                  tune.bvh_passes ? tune.bvh_passes - 1u : default_bvh_passes(n_objects), s->bvh);
         slot_object = s->bvh.slot_object;
         if (n_objects >= 0x00ffffffu) {
             set_error("rtmi_scene_create: too many objects (leaf references hold 24-bit slots)");

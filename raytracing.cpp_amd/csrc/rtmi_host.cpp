@@ -254,12 +254,20 @@ struct Prim {
 inline float down(float v) { return std::nextafter(v, -std::numeric_limits<float>::infinity()); }
 inline float up(float v) { return std::nextafter(v, std::numeric_limits<float>::infinity()); }
 
+// The tree while it is built and optimised: explicit nodes (leaves included) with parent links and exact float boxes.
+struct TNode {
+    Box box;
+    int32_t parent = -1;
+    int32_t c[2] = {-1, -1};       // children; -1: this node is a leaf
+    uint32_t first = 0, count = 0; // leaf: its objects are leaf_objs[first, first + count)
+    int32_t height = 0;            // internal levels of the subtree (leaf: 0) -- the walk's stack needs one entry per level
+};
+
 struct Builder {
     std::vector<Prim> prims;
-    std::vector<rtmi_bvh_node> nodes;
-    std::vector<uint32_t> slots;
+    std::vector<TNode> tree;
+    std::vector<uint32_t> leaf_objs;
     uint32_t leaf_size;
-    uint32_t depth = 0;
 
     static void set_child(rtmi_bvh_node& nd, int k, const Box& b, uint32_t ref) {
         for (int i = 0; i < 3; ++i) {
@@ -272,8 +280,8 @@ struct Builder {
         nd.child[k] = ref;
     }
 
-    // returns the reference (leaf or node index) of the subtree over prims[begin, end) and its box
-    uint32_t build(uint32_t begin, uint32_t end, uint32_t level, Box& box_out) {
+    // top-down greedy SAH over prims[begin, end); returns the index of the subtree's node
+    int32_t build(uint32_t begin, uint32_t end, uint32_t level) {
         Box box;
         box.reset();
         Box cbox;
@@ -285,16 +293,19 @@ struct Builder {
                 cbox.hi[a] = std::max(cbox.hi[a], prims[i].c[a]);
             }
         }
-        box_out = box;
         const uint32_t n = end - begin;
+        const int32_t me = static_cast<int32_t>(tree.size());
+        tree.emplace_back();
+        tree[me].box = box;
         if (n <= leaf_size) {
-            const uint32_t first = static_cast<uint32_t>(slots.size());
-            for (uint32_t i = begin; i < end; ++i) slots.push_back(prims[i].object);
-            return make_leaf_ref(first, n);
+            tree[me].first = static_cast<uint32_t>(leaf_objs.size());
+            tree[me].count = n;
+            for (uint32_t i = begin; i < end; ++i) leaf_objs.push_back(prims[i].object);
+            return me;
         }
-        depth = std::max(depth, level + 1);
 
-        // split: full-sweep SAH on the three axes for small ranges / shallow levels, median split otherwise
+        // split: full-sweep SAH on the three axes for small ranges, binned SAH (32 bins per axis) for large ones, a median
+        // split where neither finds a plane (coincident centres) or the tree gets too deep
         uint32_t mid = begin + n / 2;
         int axis = 0;
         {
@@ -343,19 +354,17 @@ struct Builder {
                 done = true;
             }
         } else if (level < 24) {
-            // binned SAH (32 bins) on the widest centroid axis
             constexpr int kBins = 32;
-            const float lo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
-            if (ext > 0.0f) {
+            float best_cost = std::numeric_limits<float>::infinity();
+            int best_k = -1, best_axis = -1;
+            for (int a = 0; a < 3; ++a) {
+                const float lo = cbox.lo[a], ext = cbox.hi[a] - cbox.lo[a];
+                if (!(ext > 0.0f)) continue;
                 Box bins[kBins];
                 uint32_t cnt[kBins] = {};
-                for (auto& b : bins) b.reset();
-                auto bin_of = [&](const Prim& p) {
-                    int k = static_cast<int>(kBins * ((p.c[axis] - lo) / ext));
-                    return std::min(std::max(k, 0), kBins - 1);
-                };
+                for (auto& bb : bins) bb.reset();
                 for (uint32_t i = begin; i < end; ++i) {
-                    const int k = bin_of(prims[i]);
+                    const int k = std::min(std::max(static_cast<int>(kBins * ((prims[i].c[a] - lo) / ext)), 0), kBins - 1);
                     bins[k].grow(prims[i].box);
                     cnt[k]++;
                 }
@@ -372,8 +381,6 @@ struct Builder {
                 }
                 acc.reset();
                 c = 0;
-                float best_cost = std::numeric_limits<float>::infinity();
-                int best_k = -1;
                 for (int k = 1; k < kBins; ++k) {
                     acc.grow(bins[k - 1]);
                     c += cnt[k - 1];
@@ -382,14 +389,18 @@ struct Builder {
                     if (cost < best_cost) {
                         best_cost = cost;
                         best_k = k;
+                        best_axis = a;
                     }
                 }
-                if (best_k > 0) {
-                    auto it = std::partition(prims.begin() + begin, prims.begin() + end,
-                                             [&](const Prim& p) { return bin_of(p) < best_k; });
-                    mid = static_cast<uint32_t>(it - prims.begin());
-                    done = mid > begin && mid < end;
-                }
+            }
+            if (best_k > 0) {
+                const int a = best_axis;
+                const float lo = cbox.lo[a], ext = cbox.hi[a] - cbox.lo[a];
+                auto it = std::partition(prims.begin() + begin, prims.begin() + end, [&](const Prim& p) {
+                    return std::min(std::max(static_cast<int>(kBins * ((p.c[a] - lo) / ext)), 0), kBins - 1) < best_k;
+                });
+                mid = static_cast<uint32_t>(it - prims.begin());
+                done = mid > begin && mid < end;
             }
         }
         if (!done) {
@@ -400,16 +411,121 @@ struct Builder {
             mid = begin + n / 2;
         }
 
-        const uint32_t me = static_cast<uint32_t>(nodes.size());
-        nodes.emplace_back();
-        Box lb, rb;
-        const uint32_t l = build(begin, mid, level + 1, lb);
-        const uint32_t r = build(mid, end, level + 1, rb);
-        rtmi_bvh_node nd{};
-        set_child(nd, 0, lb, l);
-        set_child(nd, 1, rb, r);
-        nodes[me] = nd;
+        const int32_t l = build(begin, mid, level + 1);
+        const int32_t r = build(mid, end, level + 1);
+        tree[me].c[0] = l;
+        tree[me].c[1] = r;
+        tree[l].parent = me;
+        tree[r].parent = me;
+        tree[me].height = 1 + std::max(tree[l].height, tree[r].height);
         return me;
+    }
+
+    // ---- post-pass: reinsertion (Bittner, Hapala & Havran, "Fast Insertion-Based Optimization of Bounding Volume
+    // Hierarchies", CGF 32(1), 2013).  A greedy top-down build fixes the upper levels before it has seen what ends up below them;
+    // here every subtree in turn (largest boxes first) is taken out of the tree -- its parent goes with it, the sibling moves
+    // up -- and put back where it adds the least surface area: the area of the new parent's box (the subtree's box joined with
+    // the box of the node it is put next to) plus what that enlarges the ancestors by, found by a best-first search over the
+    // tree bounded from below by the area already induced.  The leaves keep their spheres; any binary tree over them yields
+    // the same frame (the walk is exact for every valid tree), so this only changes how many boxes a ray meets:
+    // the expected number of boxes a random ray tests is proportional to the sum of the internal nodes' areas.
+    // The tree may not get deeper than `max_height`: the walk's LDS stack is sized from it.
+    double inner_area() const {
+        double sum = 0.0;
+        for (const TNode& t : tree) {
+            if (t.c[0] >= 0) sum += t.box.half_area();
+        }
+        return sum;
+    }
+    void refit_up(int32_t at) {
+        for (; at >= 0; at = tree[at].parent) {
+            TNode& t = tree[at];
+            t.box = tree[t.c[0]].box;
+            t.box.grow(tree[t.c[1]].box);
+            t.height = 1 + std::max(tree[t.c[0]].height, tree[t.c[1]].height);
+        }
+    }
+    static float joined_area(const Box& a, const Box& b) {
+        Box u = a;
+        u.grow(b);
+        return u.half_area();
+    }
+    uint32_t optimise(int32_t root, int32_t max_height, uint32_t max_passes) {
+        struct Cand {
+            float induced;
+            int32_t node, depth;
+            bool operator<(const Cand& o) const { return induced > o.induced; } // min-heap on the induced area
+        };
+        std::vector<Cand> heap;
+        std::vector<std::pair<float, int32_t>> order;
+        uint32_t moved_total = 0;
+        double area_before = inner_area();
+        for (uint32_t pass = 0; pass < max_passes; ++pass) {
+            order.clear();
+            for (int32_t i = 0; i < static_cast<int32_t>(tree.size()); ++i) {
+                if (i != root && tree[i].parent != root) order.emplace_back(-tree[i].box.half_area(), i);
+            }
+            std::sort(order.begin(), order.end()); // largest area first, ties by index: deterministic
+            uint32_t moved = 0;
+            for (const auto& oc : order) {
+                const int32_t nd = oc.second;
+                const int32_t par = tree[nd].parent;
+                if (par < 0 || par == root) continue; // (became a child of the root meanwhile)
+                const int32_t grand = tree[par].parent;
+                const int32_t sib = tree[par].c[0] == nd ? tree[par].c[1] : tree[par].c[0];
+                // take nd and its parent out: the sibling moves up
+                tree[grand].c[tree[grand].c[0] == par ? 0 : 1] = sib;
+                tree[sib].parent = grand;
+                refit_up(grand);
+                // best-first search for the node to put it next to
+                const Box& nb = tree[nd].box;
+                const float n_area = nb.half_area();
+                const int32_t n_height = tree[nd].height;
+                float best_cost = std::numeric_limits<float>::infinity();
+                int32_t best = -1;
+                heap.clear();
+                heap.push_back(Cand{0.0f, root, 0});
+                while (!heap.empty()) {
+                    std::pop_heap(heap.begin(), heap.end());
+                    const Cand c = heap.back();
+                    heap.pop_back();
+                    if (c.induced + n_area >= best_cost) break; // nothing left can be cheaper
+                    const TNode& x = tree[c.node];
+                    const float direct = joined_area(x.box, nb);
+                    const float total = c.induced + direct;
+                    if (total < best_cost && c.node != root && c.depth + 1 + std::max(n_height, x.height) <= max_height) {
+                        best_cost = total;
+                        best = c.node;
+                    }
+                    if (x.c[0] >= 0) {
+                        const float child_induced = total - x.box.half_area();
+                        if (child_induced + n_area < best_cost) {
+                            for (int k = 0; k < 2; ++k) {
+                                heap.push_back(Cand{child_induced, x.c[k], c.depth + 1});
+                                std::push_heap(heap.begin(), heap.end());
+                            }
+                        }
+                    }
+                }
+                if (best < 0) best = sib; // (cannot happen: the old place is always admissible) put it back
+                if (best != sib) ++moved;
+                // the freed parent node takes `best`'s place, with `best` and nd as its children
+                const int32_t bp = tree[best].parent;
+                tree[bp].c[tree[bp].c[0] == best ? 0 : 1] = par;
+                tree[par].parent = bp;
+                tree[par].c[0] = best;
+                tree[par].c[1] = nd;
+                tree[best].parent = par;
+                tree[nd].parent = par;
+                refit_up(par);
+            }
+            moved_total += moved;
+            const double area_after = inner_area();
+            const bool converged = area_after > 0.998 * area_before || moved == 0;
+            area_before = area_after;
+            if (converged) break;
+        }
+        return moved_total;
     }
 };
 
@@ -436,7 +552,7 @@ bool pad_refine_pays(const float (*classes)[8], uint32_t n_classes, float pad_ep
     return false;
 }
 
-void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& out) {
+void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, uint32_t optimise_passes, Bvh& out) {
     Builder b;
     b.leaf_size = std::min(std::max(leaf_size, 1u), kMaxLeafSize);
     b.prims.resize(n);
@@ -455,38 +571,64 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& 
         rmin_all = std::min(rmin_all, r);
         rmax_all = std::max(rmax_all, r);
     }
-    b.nodes.reserve(n);
-    b.slots.reserve(n);
-    Box root_box;
-    out.root_ref = n ? b.build(0, n, 0, root_box) : make_leaf_ref(0, 0);
-    out.nodes = std::move(b.nodes);
-    out.slot_object = std::move(b.slots);
-    out.depth = b.depth;
-    // Breadth-first numbering: the levels every ray walks through sit next to each other, which keeps them in the
-    // same few cache lines for scenes that are read from HBM (rtmi_device.hip, BIG variant).
-    if (!out.nodes.empty() && !(out.root_ref & kLeafBit)) {
-        const uint32_t nn = static_cast<uint32_t>(out.nodes.size());
-        std::vector<uint32_t> order;
-        order.reserve(nn);
-        std::vector<uint32_t> new_index(nn, 0u);
-        order.push_back(out.root_ref);
-        for (size_t head = 0; head < order.size(); ++head) {
-            const rtmi_bvh_node& nd = out.nodes[order[head]];
-            for (int k = 0; k < 2; ++k) {
-                if (!(nd.child[k] & kLeafBit)) order.push_back(nd.child[k]);
+    b.tree.reserve(2 * static_cast<size_t>(n) + 1);
+    b.leaf_objs.reserve(n);
+    out.nodes.clear();
+    out.slot_object.clear();
+    out.depth = 0;
+    if (n == 0) {
+        out.root_ref = make_leaf_ref(0, 0);
+    } else {
+        const int32_t root = b.build(0, n, 0);
+        // (the post-pass may not deepen the tree: the stack of every lane is sized from its height, and on S-RTOW three more
+        // levels would push the scene out of LDS)
+        if (optimise_passes && b.tree[root].c[0] >= 0) b.optimise(root, b.tree[root].height, optimise_passes);
+        out.depth = static_cast<uint32_t>(b.tree[root].height);
+        // slots in depth-first leaf order: the spheres of neighbouring leaves are neighbours in memory
+        std::vector<uint32_t> leaf_ref(b.tree.size(), 0u);
+        out.slot_object.reserve(n);
+        {
+            std::vector<int32_t> stack{root};
+            while (!stack.empty()) {
+                const int32_t at = stack.back();
+                stack.pop_back();
+                const TNode& t = b.tree[at];
+                if (t.c[0] < 0) {
+                    leaf_ref[at] = make_leaf_ref(static_cast<uint32_t>(out.slot_object.size()), t.count);
+                    for (uint32_t q = 0; q < t.count; ++q) out.slot_object.push_back(b.leaf_objs[t.first + q]);
+                } else {
+                    stack.push_back(t.c[1]);
+                    stack.push_back(t.c[0]);
+                }
             }
         }
-        for (uint32_t i = 0; i < nn; ++i) new_index[order[i]] = i;
-        std::vector<rtmi_bvh_node> renum(nn);
-        for (uint32_t i = 0; i < nn; ++i) {
-            rtmi_bvh_node nd = out.nodes[order[i]];
-            for (int k = 0; k < 2; ++k) {
-                if (!(nd.child[k] & kLeafBit)) nd.child[k] = new_index[nd.child[k]];
+        if (b.tree[root].c[0] < 0) {
+            out.root_ref = leaf_ref[root];
+        } else {
+            // Internal nodes numbered breadth-first: the levels every ray walks through sit next to each other -- the first
+            // few hundred are what the kernels of HBM-resident scenes stage into LDS (rtmi_device.hip, lds_top_nodes).
+            std::vector<int32_t> order;
+            std::vector<uint32_t> index(b.tree.size(), 0u);
+            order.push_back(root);
+            for (size_t head = 0; head < order.size(); ++head) {
+                const TNode& t = b.tree[order[head]];
+                for (int k = 0; k < 2; ++k) {
+                    if (b.tree[t.c[k]].c[0] >= 0) order.push_back(t.c[k]);
+                }
             }
-            renum[i] = nd;
+            for (size_t i = 0; i < order.size(); ++i) index[order[i]] = static_cast<uint32_t>(i);
+            out.nodes.resize(order.size());
+            for (size_t i = 0; i < order.size(); ++i) {
+                const TNode& t = b.tree[order[i]];
+                rtmi_bvh_node nd{};
+                for (int k = 0; k < 2; ++k) {
+                    const TNode& ch = b.tree[t.c[k]];
+                    Builder::set_child(nd, k, ch.box, ch.c[0] >= 0 ? index[t.c[k]] : leaf_ref[t.c[k]]);
+                }
+                out.nodes[i] = nd;
+            }
+            out.root_ref = 0;
         }
-        out.nodes = std::move(renum);
-        out.root_ref = 0;
     }
 
     // Per-ray pad (derivation: DESIGN.md, "Exactness of the BVH").  With u = 2^-24, L = |C - O| and M = max(L, R), the
@@ -586,6 +728,14 @@ extern "C" int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, ui
                               rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref,
                               uint32_t* depth, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,
                               float* pad_floor) {
+    return rtmi_bvh_build_passes(objects, n_objects, leaf_size, 0u, nodes_out, n_nodes, slots_out, root_ref, depth,
+                                 pad_classes_out, n_classes, pad_eps, pad_floor);
+}
+
+extern "C" int rtmi_bvh_build_passes(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, uint32_t bvh_passes,
+                                     rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref,
+                                     uint32_t* depth, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,
+                                     float* pad_floor) {
     if (n_objects && !objects) {
         set_error("rtmi_bvh_build: null objects");
         return RTMI_ERR_BAD_ARG;
@@ -601,7 +751,8 @@ extern "C" int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, ui
     }
     Bvh bvh;
     try {
-        build_bvh(objects, n_objects, leaf_size ? leaf_size : (n_objects > 0x2000u ? 4u : 2u), bvh); // (the default of rtmi_scene_create)
+        build_bvh(objects, n_objects, leaf_size ? leaf_size : (n_objects > 0x2000u ? 4u : 2u), // (the defaults of rtmi_scene_create)
+                  bvh_passes ? bvh_passes - 1u : default_bvh_passes(n_objects), bvh);
     } catch (const std::bad_alloc&) {
         set_error("rtmi_bvh_build: out of host memory");
         return RTMI_ERR_OOM;

@@ -45,7 +45,13 @@ struct Bvh {
 };
 
 void set_error(const std::string& msg);
-void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, Bvh& out);
+// Reinsertion passes after the top-down SAH build (rtmi_tuning::bvh_passes = 0).  Measured with the oracle's instrumented walk
+// (tools/tree_score.py, profiles/r04_tree_quality.txt): the greedy full-sweep SAH trees of these sphere fields are already at a
+// local optimum of the surface-area sum -- one pass moves 3 of 574 subtrees on S-RTOW (84.90 -> 84.68 box tests per sample)
+// and 351 of 65 838 on the 100k-sphere grid (461.12 -> 461.22, +40 ms of build) -- so: two passes where they cost a
+// millisecond, none on trees that stay in HBM.
+inline uint32_t default_bvh_passes(uint32_t n_objects) { return n_objects > 0x2000u ? 0u : 2u; }
+void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, uint32_t optimise_passes, Bvh& out);
 bool pad_refine_pays(const float (*classes)[8], uint32_t n_classes, float pad_eps);
 
 } // namespace rtmi

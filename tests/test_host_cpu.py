@@ -142,8 +142,8 @@ def test_tuning_struct_layout_and_unknown_knobs(pkg):
         assert "getenv" not in open(os.path.join(ROOT, "raytracing.cpp_amd", "csrc", src)).read()
 
 
-def _check_bvh(pkg, objs, leaf):
-    b = pkg.bvh_build(objs, leaf)
+def _check_bvh(pkg, objs, leaf, passes=0):
+    b = pkg.bvh_build(objs, leaf, passes)
     n = len(objs)
     assert sorted(b["slots"].tolist()) == list(range(n))  # every object in exactly one leaf slot
     nodes = b["nodes"]
@@ -195,6 +195,17 @@ def test_bvh_builder_invariants(pkg, rtow):
     dup = np.concatenate([rtow[0][4:5]] * 9)  # identical spheres: splits must still terminate
     dup["material"] = 0
     _check_bvh(pkg, dup, 2)
+    # the reinsertion post-pass (rtmi_tuning::bvh_passes: n - 1 passes, 1 = the plain top-down tree) keeps every invariant,
+    # never deepens the tree (the walk's stack is sized from its depth) and never grows the sum of the boxes' areas
+    def area(b):
+        h = b["nodes"]["half"].astype(np.float64)
+        return float((h[..., 0] * h[..., 1] + h[..., 1] * h[..., 2] + h[..., 2] * h[..., 0]).sum())
+    for objs in (rtow[0], random_spheres(3000, seed=3)[0], cornell_like()[0], dup):
+        plain = _check_bvh(pkg, objs, 2, passes=1)
+        for passes in (2, 9):
+            opt = _check_bvh(pkg, objs, 2, passes=passes)
+            assert opt["depth"] <= plain["depth"] and len(opt["nodes"]) == len(plain["nodes"])
+            assert area(opt) <= area(plain) * (1 + 1e-6)
 
 
 @pytest.mark.parametrize("height,block,world", [(1080, 8, 1), (1080, 8, 8), (675, 8, 2), (675, 8, 4), (225, 16, 8),
