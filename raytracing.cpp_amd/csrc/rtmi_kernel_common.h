@@ -35,7 +35,7 @@ struct RtmiLaunch {
     const uint4* spheres;  // [n_slots] {cx, cy, cz, r*r} as bits
     const uint4* aux;      // [n_slots] {object index, material handle, radius bits, MaterialKind of that handle}
     const uint4* mats;     // [n_mats]  {p0, p1, p2, p3} (albedo + fuzz, or refraction index in p0); the kind rides in aux.w
-    const uint4* nodes;    // [n_nodes] 4 x uint4 per node (rtmi_bvh_node)
+    const uint4* nodes;    // [n_nodes] 3 x uint4 per node (48-byte records, see unpack_node48)
     uint32_t n_slots, n_mats, n_nodes, root_ref;
     uint32_t pre_leaf[4];     // leaves hanging off the top of the tree (the ground sphere): tested at segment set-up
     uint32_t n_pre_leaves;    // root_ref == kNoWalk: they were the whole tree
@@ -79,9 +79,9 @@ DEV uint32_t fdiv(uint32_t n, const FastDiv f) {
     return (t1 + ((n - t1) >> f.sh1)) >> f.sh2;
 }
 
-// HBM-resident scenes (BIG kernels) read 48-byte node records: both centres fp32, the six half extents fp16 (rounded up
-// on the host), two child references.  Config 4 is bound by the rate of its node reads, not by their latency (touching
-// the children one step ahead made it 32 % slower): three 16-byte reads per step instead of four.
+// The node record on the device, in LDS and in HBM, is 48 bytes: both centres fp32, the six half extents fp16 (rounded up on the
+// host), two child references -- three 16-byte reads per step.  (Rounds 1-3 kept 64-byte all-fp32 records for trees in LDS;
+// see walk_nodes_lds in rtmi_device.hip for the A/B that retired them.)
 struct NodeFields {
     float c0x, c0y, c0z, c1x, c1y, c1z, h0x, h0y, h0z, h1x, h1y, h1z;
     uint32_t ch0, ch1;
@@ -98,17 +98,6 @@ DEV NodeFields unpack_node48(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
     n.ch0 = c1; n.ch1 = c2;
     return n;
 }
-DEV NodeFields unpack_node64(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b0, uint32_t b1, uint32_t b2,
-                             uint32_t b3, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t d0, uint32_t d1) {
-    NodeFields n; // rtmi_bvh_node: ctr[2][3] | half[2][3] | child[2] | reserved[2]
-    n.c0x = __uint_as_float(a0); n.c0y = __uint_as_float(a1); n.c0z = __uint_as_float(a2);
-    n.c1x = __uint_as_float(a3); n.c1y = __uint_as_float(b0); n.c1z = __uint_as_float(b1);
-    n.h0x = __uint_as_float(b2); n.h0y = __uint_as_float(b3); n.h0z = __uint_as_float(c0);
-    n.h1x = __uint_as_float(c1); n.h1y = __uint_as_float(c2); n.h1z = __uint_as_float(c3);
-    n.ch0 = d0; n.ch1 = d1;
-    return n;
-}
-
 
 // In-kernel stamps (diagnostic build only, -DRTMI_PROF): s_memtime deltas per phase of the v1 kernel, summed per wave
 // into stats[8 + i].  Never compiled into the shipped library.
