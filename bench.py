@@ -117,6 +117,7 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="CPU rehearsal of the launcher and the gather plumbing (no render, no GPU, value = 0)")
     ap.add_argument("--rehearse-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--rehearse-height", type=int, default=101, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -188,7 +189,7 @@ def rehearse(args, world, rank):
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     if rank == args.rehearse_fail_rank:
         raise SystemExit(7)
-    H, W = 101, 16
+    H, W = args.rehearse_height, 16
     plan = pkg.RowShardPlan(H, BLOCK_ROWS, world)
     y_first, n_blocks, rows = plan.shard(rank)
     local = torch.full((plan.max_rows, W, 3), -1.0)
@@ -204,7 +205,8 @@ def rehearse(args, world, rank):
         print(json.dumps({"metric": "launcher rehearsal (no render)", "value": 0.0, "unit": "Msamples/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True,
                           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "none"}, "rehearsal": True,
+                          "config": {"workload": "none"}, "rehearsal": True, "rows": H,
+                          "blocks_per_rank": [s_[1] for s_ in plan.shards],
                           "ranks": world, "backend": dist.get_backend() if world > 1 else "none"}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -476,7 +478,10 @@ def main(argv=None):
                 for k in ctr:
                     ctr[k] += c[k]
         fps = flops_per_sample(ctr)
-        chain_words = scene.launch_info()["packed_chains"] if scene is not None else 0
+        # (what was launched, not what the scene is eligible for: a launch whose chain slots could not be allocated falls back
+        # to run-length encoded chains and says so in packed_chain_fallbacks)
+        li = scene.launch_info() if scene is not None else {}
+        chain_words = li.get("packed_chains", 0) if li.get("packed_chain_fallbacks", 0) == 0 else 0
         chain_bytes = 0.0
         if chain_words:
             bits = max(1, int(np.ceil(np.log2(max(2, len(mats))))))
@@ -515,7 +520,7 @@ def main(argv=None):
             # pass reads them back) + framebuffer slice; the path is VALU-bound, HBM is reported as a sanity check
             # + in packed-chain launches the material handles a path leaves for the resolve pass (its non-dielectric bounces x
             # ceil(log2 n_materials) bits; the slot the launch reserves per sample is chain_words x 4 bytes)
-            "hbm_algorithmic_bytes_per_launch": int(len(objs) * (16 + 16 + 32) + (0 if bvh is None else len(bvh["nodes"]) * 64)
+            "hbm_algorithmic_bytes_per_launch": int(len(objs) * (16 + 16 + 32) + (0 if bvh is None else len(bvh["nodes"]) * 48)
                                                     + samples_per_launch * (16 + chain_bytes) + W * (H // n_gpus) * 16),
             "chain_words_per_sample": chain_words,
             "note": "fp32 VALU-bound path (SURVEY 8d): peak = non-FMA issue rate 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",

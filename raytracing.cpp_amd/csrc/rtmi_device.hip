@@ -1114,7 +1114,13 @@ __global__ void __launch_bounds__(256) rtmi_resolve_chain_kernel(const ResolveAr
                     tile[q * kResRow + lane] = make_float4(color.x, color.y, color.z, 0.0f);
                 }
             }
-            // (a wave's LDS accesses are ordered: no barrier between the phases of one wave)
+            // the tile passes colours between the lanes of ONE wave: the hardware keeps a wave's LDS accesses in order, the
+            // language's memory model needs to be told -- a wavefront-scope release / acquire pair around a wave barrier (no
+            // instruction on gfx950 beyond the waitcnt the reads need anyway) keeps the compiler from moving the row reads above
+            // the tile writes, or the next block's writes above these reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (lane < np) {
                 const float4* row = tile + lane * kResRow;
                 for (uint32_t i = 0; i < cnt; ++i) {
@@ -1122,6 +1128,9 @@ __global__ void __launch_bounds__(256) rtmi_resolve_chain_kernel(const ResolveAr
                     sum = vadd(sum, mk(c.x, c.y, c.z));
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (lane < np) resolve_store(A, p0 + lane, sum);
     }

@@ -26,6 +26,26 @@ def test_gpus_2_spawns_two_ranks_and_relays_rank0_line():
     assert doc["n_gpus"] == 2 and doc["ranks"] == 2 and doc["backend"] == "gloo" and doc["rehearsal"] is True
 
 
+def test_world_8_ragged_shards_and_ranks_without_a_block():
+    """The driver's first multi-GPU run is world 8: 1080 rows = 135 blocks of 8 (ranks 0-6 render 17 blocks, rank 7 renders 16),
+    and an image of 7 rows leaves ranks 1-7 without a block; rank-major packed gather, scanline order checked on rank 0."""
+    for height, want_blocks in ((1080, [17] * 7 + [16]), (7, [1] + [0] * 7)):
+        p = _run(["--gpus", "8", "--rehearse-launch", "--rehearse-height", str(height), "--steps", "1", "--warmup", "0"])
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        doc = json.loads(lines[0])
+        assert doc["n_gpus"] == 8 and doc["ranks"] == 8 and doc["rows"] == height and doc["blocks_per_rank"] == want_blocks
+
+
+def test_world_8_a_failing_rank_or_a_wrong_rank_count_fails_the_launcher():
+    p = _run(["--gpus", "8", "--rehearse-launch", "--rehearse-fail-rank", "5"])
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    p = _run(["--gpus", "8", "--rehearse-launch"], WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr and not p.stdout.strip()
+
+
 def test_a_failing_rank_fails_the_launcher():
     p = _run(["--gpus", "2", "--rehearse-launch", "--rehearse-fail-rank", "1"])
     assert p.returncode != 0

@@ -57,3 +57,47 @@ def test_sharded_render_gathers_to_the_full_frame(tmp_path, ob, world, width):
     want, _ = ob.render_rect_counter(cam, objs, mats, 5, 0, 0, cam.img_width, cam.img_height, nthreads=4)
     got = np.load(out)
     assert got.shape == want.shape and got.tobytes() == want.tobytes()
+
+
+def _plan_worker(rank, world, port, height, width, out_path):
+    """As _worker, with a synthetic renderer (pixel value = its absolute row and column): the shard plan, the rank-major
+    gather and the de-interleave at the driver's own geometry, where the oracle would take minutes per rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import rtmi_loader
+    pkg = rtmi_loader.load()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = pkg.RowShardPlan(height, 8, world)
+        y_first, n_blocks, rows = plan.shard(rank)
+        local = torch.full((plan.max_rows, width, 3), -1.0)
+        cols = torch.arange(width, dtype=torch.float32)
+        loc = 0
+        for k in range(n_blocks):
+            y0 = y_first + k * world * 8
+            for y in range(y0, min(height, y0 + 8)):
+                local[loc, :, 0] = float(y)
+                local[loc, :, 1] = cols
+                local[loc, :, 2] = float(rank)
+                loc += 1
+        assert loc == rows
+        frame = pkg.gather_frame(local, plan, rank)
+        if rank == 0:
+            np.save(out_path, frame.numpy())
+        else:
+            assert frame is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height", [1080, 7, 64])
+def test_world_8_shard_plan_gathers_to_scanline_order(tmp_path, height):
+    """World 8 (the driver's scaling run): 1080 rows = 135 blocks, ragged (ranks 0-6: 17 blocks, rank 7: 16); 7 rows: ranks 1-7
+    render nothing; 64 rows: one block each."""
+    world, width = 8, 24
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_plan_worker, args=(world, _free_port(), height, width, out), nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape == (height, width, 3)
+    assert np.array_equal(got[:, 0, 0], np.arange(height, dtype=np.float32))  # scanline order
+    assert np.array_equal(got[0, :, 1], np.arange(width, dtype=np.float32))
+    assert np.array_equal(got[:, 0, 2], (np.arange(height) // 8 % world).astype(np.float32))  # block b came from rank b mod 8

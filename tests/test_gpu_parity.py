@@ -1084,18 +1084,31 @@ def test_config4_full_size(pkg, ob, gpu):
 
 
 def test_config5_full_size(pkg, ob, gpu):
-    """BASELINE configs[4] at its own size: 800x800, 4096 spp, 200 bounces.  Its 42 GB of sample records exceed the
-    library's 24 GB buffer cap, so the call runs in two bands of rows without any override; a row range rendered on
-    its own (one band) gives the same bits, and 16 pixels equal the oracle."""
+    """BASELINE configs[4] at its own size: 800x800, 4096 spp, 200 bounces, rendered the way the library and bench.py do by
+    default (RTMI_ACCEL_AUTO: the linear scan for a 7-sphere scene, packed attenuation chains multiplied by the resolve pass) and
+    with the BVH walk.  The 42 GB of sample records + 210 GB of chain slots exceed the library's 24 GB buffer cap, so the call
+    runs in bands of rows without any override (ten with the chain slots); both renders give the same bits, a row range rendered
+    on its own (one band, straddling a band boundary of the full call) gives the same bits, and 16 pixels equal the oracle."""
     objs, mats, kw = cornell_like()
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
     assert (cam.img_width, cam.img_height, cam.samples_per_pixel, cam.maxdepth) == (800, 800, 4096, 200)
     assert 800 * 800 * 4096 * 16 > 24 << 30  # needs the banded path
-    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as s:
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_AUTO) as s:  # what bench.py --config 5 times
+        li = s.launch_info()
+        assert s.accel == pkg.ACCEL_BRUTE and li["packed_chains"] > 0
         rgb, rgba = s.render_rows(0, 800, 55)
-        assert s.last_kernel_ms() > 1000.0
-        part, part8 = s.render_rows(392, 408, 55)  # straddles the band boundary of the full call
-    assert rgb[392:408].tobytes() == part.tobytes() and np.array_equal(rgba[392:408], part8)
+        assert s.last_kernel_ms() > 500.0
+        assert s.launch_info()["packed_chain_fallbacks"] == 0 and s.launch_info()["whole_pixel_fallbacks"] == 0
+        # rows per band of the full call: 24 GB / (800 px x 4096 spp x (16 B record + chain slot))
+        per_row = 800 * 4096 * (16 + 4 * li["packed_chains"])
+        n_bands = -(-800 // ((24 << 30) // per_row))
+        band = -(-800 // n_bands)
+        assert n_bands >= 8
+        part, part8 = s.render_rows(band - 8, band + 8, 55)  # straddles the first band boundary of the full call
+    assert rgb[band - 8:band + 8].tobytes() == part.tobytes() and np.array_equal(rgba[band - 8:band + 8], part8)
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as s:
+        walk, walk8 = s.render_rows(0, 800, 55)
+    assert walk.tobytes() == rgb.tobytes() and np.array_equal(walk8, rgba)
     assert np.isfinite(rgb).all() and 0.001 < float(rgb.mean()) < 1.0  # a dark box: light enters through the opening only
     rng = np.random.default_rng(45)
     for x, y in zip(rng.integers(0, 800, 16), rng.integers(0, 800, 16)):
