@@ -2,7 +2,7 @@
 on a strip of the S-GRID (config 4) and S-RTOW (config 3) frames, and whether the frame still equals the one rendered
 with the round 1-3 class pad (oracle pad mode 1).  VERDICT r3 #1: "score candidates on the CPU first".
 
-usage: python tools/pad_score.py [grid|rtow|both] [rows] [spp]
+usage: python tools/pad_score.py [grid|rtow|both] [rows per strip] [spp]
 """
 import os
 import sys
@@ -17,7 +17,7 @@ pkg = rtmi_loader.load()
 from oracle import binding as ob  # noqa: E402
 
 
-def score(name, objs, mats, kw, rows, spp, leaf, y0):
+def score(name, objs, mats, kw, rows, spp, leaf, y_list):
     kw = dict(kw, samples_per_pixel=spp)
     ocam = ob.camera_setup(ob.camera_params(**kw))
     bvh = pkg.bvh_build(objs, leaf)
@@ -27,14 +27,20 @@ def score(name, objs, mats, kw, rows, spp, leaf, y0):
     for mode in (1, 2, 3, 0):  # class pad, refined, none (not exact), auto (the product's choice)
         ob.set_pad_mode(mode)
         t0 = time.time()
-        rgb, _, c = ob.render_rect_counter(ocam, objs, mats, 404, 0, y0, W, y0 + rows, nthreads=8, counters=True, bvh=bvh)
+        c, frames = {}, []
+        for y0 in y_list:  # strips spread over the frame
+            strip, _, cs = ob.render_rect_counter(ocam, objs, mats, 404, 0, y0, W, y0 + rows, nthreads=8, counters=True, bvh=bvh)
+            frames.append(strip)
+            for k, v in cs.items():
+                c[k] = c.get(k, 0) + v
+        rgb = np.concatenate(frames)
         dt = time.time() - t0
         if base is None:
             base = rgb
         diff = int((np.nan_to_num(rgb).view(np.uint32) != np.nan_to_num(base).view(np.uint32)).any(axis=-1).sum())
         n = c["samples"]
         print(f"{name} leaf={leaf} pad_mode={mode}: {c['sphere_tests'] / n:8.2f} sphere + {c['node_tests'] / n:8.2f} box tests "
-              f"/ sample, {c['segments'] / n:.3f} segments; pixels differing from mode 1: {diff} of {rows * W}  ({dt:.1f} s)",
+              f"/ sample, {c['segments'] / n:.3f} segments; pixels differing from mode 1: {diff} of {len(y_list) * rows * W}  ({dt:.1f} s)",
               flush=True)
     ob.set_pad_mode(0)
 
@@ -45,11 +51,11 @@ def main():
     spp = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     if what in ("grid", "both"):
         objs, mats, kw = pkg.workloads.big_grid(316)
-        score("S-GRID", objs, mats, kw, rows, spp, 4, 700)
+        score("S-GRID", objs, mats, kw, rows, spp, 4, [400, 600, 800, 1000])
     if what in ("rtow", "both"):
         objs, mats = pkg.make_world_spheres(12345)
         kw = dict(image_width=1920, max_depth=50)
-        score("S-RTOW", objs, mats, kw, rows, spp, 2, 700)
+        score("S-RTOW", objs, mats, kw, rows, spp, 2, [300, 500, 700, 900, 1060])
 
 
 if __name__ == "__main__":
