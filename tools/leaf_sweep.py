@@ -12,7 +12,7 @@ else:
     objs, mats = pkg.make_world_spheres(12345)
     kw = dict(image_width=1920, samples_per_pixel=spp, max_depth=50)
 cam = pkg.camera_setup(pkg.camera_params(**kw))
-for leaf in ((4, 5, 6, 8) if which == "grid" else (1, 2, 3, 4)):
+for leaf in ((2, 3, 4) if which == "grid" else (1, 2, 3, 4)):  # (kMaxLeafSize = 4)
     with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, leaf_size=leaf) as sc:
         ms = []
         for _ in range(3):
