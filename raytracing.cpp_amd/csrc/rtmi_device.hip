@@ -1345,7 +1345,11 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     P.n_chunks = 1;
     P.sample_buf = nullptr;
     const size_t sample_floats = (size_t)n_local_rows * W * spp; // float4 records
-    // chunk size: aim at ~128 work items per lane of the persistent grid, never below 3 samples.  The end of a launch is
+    // chunk size: aim at ~128 work items per lane of the persistent grid, never below 4 samples (round 4: the eighth of the frame
+    // one of 8 GPUs renders, trace-kernel ms for chunks of 2 / 3 / 4 / 5 / 6 / 8: 19.26 / 18.30 / 17.90 / 17.96 / 18.29 / 18.82;
+    // handing the work out in two phases -- long chunks, then a tail of short ones -- was built and measured no better than the
+    // best single size at any shard size, profiles/r04_two_phase_chunks.txt: what bounds the chunk is not the end of the launch
+    // but the heavy-tailed items of the horizon band, which start in the middle of it).  The end of a launch is
     // a tail of lanes finishing their last item while the others idle, so items must be short next to the launch
     // (A/B on MI355X, 1080p x 512 spp, ms per launch: whole frame 4: 223.1, 8: 219.1, 16: 217.8, 24: 217.6, 32: 219.0,
     // 86: 235.4; the eighth of the frame one of 8 GPUs renders 2: 28.5, 3: 28.0, 4: 28.0, 6: 28.6, 16: 36.2;
@@ -1356,7 +1360,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         const uint64_t want_items = 128ull * s->grid * s->block;
         const uint64_t pixels = (uint64_t)n_local_rows * W;
         const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, (want_items + pixels - 1) / pixels);
-        chunk = std::max(3u, (spp + n_chunks - 1u) / std::max(1u, n_chunks));
+        chunk = std::max(4u, (spp + n_chunks - 1u) / std::max(1u, n_chunks));
     }
     if (chunk && spp > chunk && sample_floats * sizeof(float4) <= s->sample_buf_cap_bytes) {
         if (sample_floats > s->samples_capacity) {
