@@ -5,8 +5,10 @@ store -- how often it runs per round (with at least one lane), with how many lan
   python tools/branch_census.py --build                 # on the CPU: librtmi_prof.so (-DRTMI_PROF) + the static counts
   python tools/branch_census.py <width> <spp> [rtow|grid|cornell]   # on the GPU box: prints the table
 
-The census build counts with wave-uniform scalars (ballot + popcount); its kernel is the C++ walk, so times differ from
-the shipped build, counts do not (same rounds: the vote rules are the same)."""
+Two diagnostic builds: -DRTMI_PROF=1 (cycle stamps and the walk's lane counts; only THIS one walks with the C++ node step, so its
+times differ from the shipped build) and -DRTMI_PROF=2 (the branch census, counted with wave-uniform scalars -- ballot + popcount --
+around the hand-written node loops of the shipped build).  Counts are those of the shipped kernel either way: same rounds, the
+vote rules are the same."""
 import ctypes as C, json, os, re, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
