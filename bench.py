@@ -24,7 +24,8 @@ renders its blocks and rank 0 gathers the framebuffer slices with ONE RCCL gathe
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      algorithmic flops per launch (SURVEY 8d formula, counters from the CPU oracle's instrumented walk
-                of the same BVH) / mean kernel duration from HIP events on the launch stream
+                of the same BVH) / mean kernel duration from HIP events on the launch stream; `traffic`: HBM-side bytes per
+                step from FETCH_SIZE / WRITE_SIZE, measured in this run by two rocprofv3 child runs of this command (N = 1)
   cpu_baseline  the oracle (a port of the reference's CPU path, reference-shaped job system) timed on this host
 """
 import os
@@ -113,6 +114,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-linear-scan", action="store_true", help="skip the extra linear-scan (reference algorithm) step")
     ap.add_argument("--no-e2e", action="store_true", help="skip the extra D2H-inclusive steps behind value_e2e")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 child runs (FETCH_SIZE / WRITE_SIZE) behind roofline.traffic; the figure of "
+                         "profiles/hbm_traffic.json is restated instead")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-stride", type=int, default=0, help="CPU baseline renders every n-th pixel in x and y")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="CPU rehearsal of the launcher and the gather plumbing (no render, no GPU, value = 0)")
@@ -156,6 +161,53 @@ def launch_ranks(args, argv):
         return 4
     print(line, flush=True)
     return 0
+
+
+def measure_traffic(args):
+    """roofline.traffic, measured in this run: HBM-side bytes of the trace kernel per step from the PMC counters, collected as
+    MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (they do not fit one), kernel trace
+    only beside them -- over child runs of this very script (first frame + one step, nothing else), started BEFORE this process
+    touches the GPU.  Returns (bytes per step, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--accel", args.accel, "--steps", "1", "--warmup", "0",
+             "--no-cpu-baseline", "--no-linear-scan", "--no-e2e", "--no-traffic", "--traffic-child"]
+    for flag, v in (("--width", args.width), ("--spp", args.spp), ("--depth", args.depth)):
+        if v:
+            child += [flag, str(v)]
+    per_frame = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="rtmi_traffic_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child,
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (exit {p.returncode})"
+            total, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                if "rtmi_trace_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                    total += float(row["Counter_Value"])
+                    n += 1
+            if n == 0 or n % 2:
+                return None, f"unexpected number of trace dispatches in the {counter} pass: {n}"
+            per_frame[counter] = (total / 2.0, n // 2)  # the child renders two frames (first frame + one step)
+        except Exception as e:  # a profiler hiccup must not cost the bench line
+            return None, f"{counter} pass: {type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    (f_kb, bands), (w_kb, _) = per_frame["FETCH_SIZE"], per_frame["WRITE_SIZE"]
+    note = (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child runs of this command, "
+            f"first frame + one step), 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950 correction of MI355X_MICROARCH.md) summed over the {bands} "
+            f"trace dispatch(es) of one step: FETCH_SIZE {f_kb:.0f} KB, WRITE_SIZE {w_kb:.0f} KB.  WRITE_SIZE tallies 64 B per write request "
+            f"and the sample records leave as lone 16-byte stores: it reads 3.65x their bytes (tools/ubench/write_size_calib.hip)")
+    return int((2.0 * f_kb + w_kb) * 1024.0), note
 
 
 def workload(pkg, cfg, args):
@@ -231,6 +283,10 @@ def main(argv=None):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.rehearse_launch:
         return rehearse(args, world, rank)
+
+    live_traffic = (None, "not measured (--no-traffic, a multi-GPU run or --single-process): the figure of profiles/hbm_traffic.json")
+    if world == 1 and not args.single_process and not args.no_traffic and not args.force_dist:
+        live_traffic = measure_traffic(args)  # child processes; this one has not touched the GPU yet
 
     import numpy as np
     import torch
@@ -377,6 +433,10 @@ def main(argv=None):
         else:
             per_rank_ms = [float(kmean.item())]
 
+    if args.traffic_child:  # a profiled child of measure_traffic(): the frames are rendered, nothing else is wanted
+        print(json.dumps({"traffic_child": True, "steps": args.steps, "kernel_ms": per_rank_ms}), flush=True)
+        scene.close()
+        return
     # ---- the metric as SURVEY 8(d) words it: wall time including the D2H copy of the float frame (+ gather) ------------
     e2e_elapsed, e2e_steps = None, 0
     if not args.no_e2e and not args.single_process:
@@ -489,15 +549,17 @@ def main(argv=None):
         kernel_s = max(per_rank_ms) / 1e3
         samples_per_launch = samples / n_gpus
         achieved = samples_per_launch * fps / kernel_s / 1e12
-        traffic, traffic_note = None, None
+        traffic, traffic_note = live_traffic
+        traffic_source = "rocprofv3 child runs of this command, in this run" if traffic is not None else None
         tpath = os.path.join(_ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if traffic is None and os.path.exists(tpath):
             try:
                 for tj in json.load(open(tpath)).get("entries", []):
                     if (tj.get("config") == args.config and tj.get("width") == W and tj.get("spp") == spp
                             and tj.get("n_gpus") == n_gpus and tj.get("accel", "bvh") == args.accel):
                         traffic = tj.get("bytes_per_launch")
-                        traffic_note = tj.get("note")
+                        traffic_note = (tj.get("note") or "") + f"  [{live_traffic[1]}]"
+                        traffic_source = "profiles/hbm_traffic.json (the builder's rocprofv3 passes of this command, restated)"
             except Exception:
                 traffic = None
         # the same work in lane-operations (what the VALU issues): a box test is 6 FMA + 18 single operations = 24, a
@@ -511,7 +573,7 @@ def main(argv=None):
             "spec_vector_peak": SPEC_VECTOR_PEAK_TFLOPS,
             "lane_op_frac": round(samples_per_launch * lane_ops / kernel_s / 1e12 / VALU_PEAK_TFLOPS, 5),
             "lane_ops_per_sample": round(lane_ops, 1),
-            "traffic": traffic, "traffic_note": traffic_note,
+            "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note,
             "kernel": "rtmi_trace_kernel<%s>" % args.accel, "kernel_ms": round(kernel_s * 1e3, 3),
             "flops_per_sample": round(fps, 1),
             "counters_per_sample": {k: round(ctr[k] / ctr["samples"], 3) for k in ctr if k not in ("samples", "hit_lambertian", "hit_metallic")},

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 echo "== bench config $CFG"
 python3 $ROOT/bench.py --config $CFG "$@" > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 cut -c1-400 $OUT/bench.json
-QUIET="--config $CFG --no-cpu-baseline --no-linear-scan --no-e2e --steps $STEPS --warmup 0"
+QUIET="--config $CFG --no-cpu-baseline --no-linear-scan --no-e2e --no-traffic --steps $STEPS --warmup 0"
 echo $((STEPS + 1)) > $OUT/frames.txt   # frames of a traced run: the first frame of the scene + the steps
 echo "== kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOT/bench.py $QUIET > $OUT/bench_kt.log 2>&1 || { echo "kernel-trace run failed"; tail -5 $OUT/bench_kt.log; exit 1; }

@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/traffic_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 0 > $OUT/bench_$c.log 2>&1 || echo "pass $c failed"
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $ROOT/bench.py --no-cpu-baseline --no-traffic --steps 2 --warmup 0 > $OUT/bench_$c.log 2>&1 || echo "pass $c failed"
 done
 python3 $ROOT/tools/summarize_prof.py $OUT 2>/dev/null | grep -E "rtmi_" || true
 for c in FETCH_SIZE WRITE_SIZE; do f=$(find $OUT/$c -name "*counter_collection.csv" | head -1); python3 - "$f" <<'PY'
