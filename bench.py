@@ -186,7 +186,7 @@ def measure_traffic(args):
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             p = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child,
-                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (exit {p.returncode})"
