@@ -329,6 +329,7 @@ def main(argv=None):
     stream = torch.cuda.current_stream(dev).cuda_stream
     kernel_ms = []
     gather_ms = []
+    gather_events = []  # torch.distributed path: (before, after) events around the gather + de-interleave of every step
     t_setup = time.perf_counter()
     if args.single_process:
         # (librccl prints a version banner on stdout when the first communicator is created: this process owes its stdout
@@ -385,9 +386,15 @@ def main(argv=None):
                 got = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, got, dst=0)
                 return split(torch.cat(got).to(dev)) if rank == 0 else (None, None)
-            # the one RCCL collective of a frame, straight into one preallocated buffer on rank 0 (rank-major slices)
+            # the one RCCL collective of a frame, straight into one preallocated buffer on rank 0 (rank-major slices);
+            # bracketed by events on the stream it runs on, so that the line can say what the gather cost
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
             dist.gather(local, gathered_parts, dst=0)
-            return split(gathered) if rank == 0 else (None, None)
+            out = split(gathered) if rank == 0 else (None, None)
+            g1.record()
+            gather_events.append((g0, g1))
+            return out
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -401,6 +408,8 @@ def main(argv=None):
     # outside the warm-up count
     t_first = time.perf_counter()
     step()
+    torch.cuda.synchronize(dev)
+    my_first_frame_ms = (time.perf_counter() - t_first) * 1e3  # this rank's own first frame, before the barrier
     sync()
     first_frame_ms = (time.perf_counter() - t_first) * 1e3
     for _ in range(args.warmup):
@@ -408,6 +417,7 @@ def main(argv=None):
     sync()
     kernel_ms.clear()
     gather_ms.clear()
+    gather_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame, frame8 = step()
@@ -421,6 +431,20 @@ def main(argv=None):
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    if gather_events:  # (all steps are done: the events have completed)
+        gather_ms.extend(a.elapsed_time(b) for a, b in gather_events)
+        gather_events.clear()
+    # what every rank saw, for a line that explains itself when N > 1: its own first frame (allocations, the cost
+    # probe), its mean trace-kernel span, its mean gather + de-interleave time (rank 0: until the frame is in scanline order;
+    # the others: until their slice has left)
+    first_frame_per_rank = [my_first_frame_ms]
+    gather_per_rank = [float(np.mean(gather_ms))] if gather_ms else None
+    if use_dist:
+        mine = torch.tensor([my_first_frame_ms, float(np.mean(gather_ms)) if gather_ms else 0.0], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        first_frame_per_rank = [float(v[0].item()) for v in allv]
+        gather_per_rank = [float(v[1].item()) for v in allv]
     # mean trace-kernel time of every rank / device
     if args.single_process:
         per_rank_ms = [float(np.mean([k[i] for k in kernel_ms])) for i in range(n_gpus)] if kernel_ms else [0.0] * n_gpus
@@ -482,6 +506,10 @@ def main(argv=None):
                        "resident": "scene+BVH in HBM before the timed region; frame stays in HBM"},
             "rccl_ranks": rccl_ranks,
             "kernel_ms_per_rank": [round(k, 3) for k in per_rank_ms],
+            "kernel_ms_note": "per rank: trace kernels of a step (HIP events on the launch stream; bands added up, resolve passes not "
+                              "included), mean over the timed steps",
+            "kernel_ms_slowest_fastest": [round(max(per_rank_ms), 3), round(min(per_rank_ms), 3)],
+            "first_frame_ms_per_rank": [round(v, 2) for v in first_frame_per_rank],
             # what `value` is: the bench contract wants inputs resident and rules a PCIe-inclusive rate out as `value`;
             # SURVEY 8(d)'s wording of the metric (D2H of the frame inside the clock) is `value_e2e` below
             "value_resident": round(value, 2),
@@ -495,6 +523,10 @@ def main(argv=None):
         }
         if gather_ms:
             out["gather_ms"] = round(float(np.mean(gather_ms)), 3)
+        if gather_per_rank is not None and use_dist:
+            out["gather_ms_per_rank"] = [round(v, 3) for v in gather_per_rank]
+            out["gather_ms_note"] = ("torch.distributed path: events around dist.gather + de-interleave on the rank's stream, behind its "
+                                     "own kernels; rank 0's figure includes waiting for the slowest rank's slice")
         if e2e_elapsed is not None:
             out["value_e2e"] = round(samples / (e2e_elapsed / e2e_steps) / 1e6, 2)
             out["value_e2e_note"] = (f"{e2e_steps} extra steps timed with the D2H copy of the {W}x{H} float frame into pinned "
@@ -541,6 +573,10 @@ def main(argv=None):
         # (what was launched, not what the scene is eligible for: a launch whose chain slots could not be allocated falls back
         # to run-length encoded chains and says so in packed_chain_fallbacks)
         li = scene.launch_info() if scene is not None else {}
+        if li:
+            out["launch"] = {"bands": li.get("bands"), "tile_order": li.get("tile_order"), "probe_us": li.get("probe_us"),
+                             "note": "the most recent call: bands of rows it was rendered in, 8x8 tiles handed out costliest first (1) or row "
+                                     "by row (0), duration of the scene's one cost probe launch (inside first_frame_ms)"}
         chain_words = li.get("packed_chains", 0) if li.get("packed_chain_fallbacks", 0) == 0 else 0
         chain_bytes = 0.0
         if chain_words:

@@ -119,7 +119,8 @@ typedef struct rtmi_tuning {
     uint32_t bvh_passes;        /* reinsertion passes over the BVH after the top-down SAH build: 0 = default (2; none above 8192 objects), n > 0 = n - 1
                                  * (1 = the plain top-down tree of rounds 1-3); any tree gives the same image.
                                  * (This slot was defer_cap until round 2 and ignored in round 3.) */
-    uint32_t sample_buf_mb;     /* cap on the sample-record buffer in MiB (default 24576); larger calls run in row bands */
+    uint32_t sample_buf_mb;     /* cap on the sample-record buffer in MiB (default: a third of the device's memory, 96 GB on MI355X;
+                                 * 24576 in rounds 2-4); a call that needs more runs in bands of rows, one after the other */
     uint32_t force_hbm_scene;   /* nonzero: leave the scene in HBM even when it fits LDS (the config-4 path) */
     uint32_t top_down;          /* nonzero: hand out tiles top row first instead of bottom row first */
     uint32_t kernel;            /* 0 / 1 = the round-based kernel; 2 asked for round 2's queue-scheduled kernel (an experiment
@@ -127,6 +128,13 @@ typedef struct rtmi_tuning {
     uint32_t reserved3[3];      /* (were wf_block_lanes / wf_slots / wf_refill, the geometry of that kernel) ignored */
     uint32_t lds_top_nodes;     /* HBM-resident trees: how many breadth-first nodes of the top of the tree each workgroup
                                  * stages into LDS (0 = default: as many as fit next to the stacks; n > 0: at most n - 1) */
+    /* ---- added in 0.5 (a caller built against the 0.4 header passes its smaller struct_size and gets the defaults) ---- */
+    uint32_t tile_order;        /* order the 8x8 tiles of a launch are handed out in: 0 = costliest first for scenes staged into LDS,
+                                 * where a launch has >= 2048 tiles and >= 16 samples per pixel (per-tile costs from one 2-spp probe
+                                 * launch per scene, made by the first such call), 1 = row by row, bottom rows first (rounds 1-4),
+                                 * 2 = costliest first always */
+    uint32_t bands;             /* a call whose sample records pass the cap (sample_buf_mb) is rendered in bands of rows, one after
+                                 * the other: 0 / 1 = as many bands as the cap asks for (one if the call fits), n > 1 = at least n */
 } rtmi_tuning;
 
 typedef struct rtmi_scene_options {
@@ -188,11 +196,24 @@ void rtmi_scene_destroy(rtmi_scene* scene);
 int rtmi_render_rows(rtmi_scene* scene, uint32_t y0, uint32_t y1, uint64_t seed, float* rgb_linear_out,
                      uint32_t* rgba8_out);
 
+/* Tile-granular entry (0.5): pixels [x0, x1) x [y0, y1) -- one RayTracingWorkPackage{u16vec2 start, end} of the reference
+ * (src/main.cc:404-407, consumed pixel by pixel at :507-519) -- into DENSE outputs of (x1 - x0) pixels per row:
+ *   rgb_linear_out  nullable, (y1-y0)*(x1-x0)*3 floats;  rgba8_out  nullable, (y1-y0)*(x1-x0) uint32 0xAABBGGRR.
+ * Same pixels, bit for bit, as the corresponding part of rtmi_render_rows (the draw streams are keyed by the absolute
+ * pixel).  Host pointers; blocking; safe to call concurrently on one scene.  A host that keeps the reference's queue of
+ * 8x8 packages unchanged calls this once per package: correct, and slow -- every call is a kernel launch, a resolve pass
+ * and a device-to-host copy for 64 pixels; row blocks (rtmi_render_rows) are the fast granularity. */
+int rtmi_render_rect(rtmi_scene* scene, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint64_t seed,
+                     float* rgb_linear_out, uint32_t* rgba8_out);
+/* Same with DEVICE output pointers, asynchronous on `hip_stream` (see rtmi_render_row_blocks_device for the stream rule). */
+int rtmi_render_rect_device(rtmi_scene* scene, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint64_t seed,
+                            void* d_rgb_linear_out, void* d_rgba8_out, void* hip_stream);
+
 /* Same, row-block sharded and device-resident (multi-GPU path): renders `n_blocks` blocks of `block_rows` rows,
  * block k covering rows [y_first + k*block_stride*block_rows, +block_rows) clipped to the image, into a dense
  * slice of n_blocks*block_rows rows.  Outputs are DEVICE pointers (either may be NULL); the launch is
  * asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).  Launches on one scene share its work
- * counter and sample buffer: issue them on ONE stream (or wait for the previous one) -- use one scene per stream
+ * counter and sample buffers: issue them on ONE stream (or wait for the previous one) -- use one scene per stream
  * for concurrent frames. */
 int rtmi_render_row_blocks_device(rtmi_scene* scene, uint32_t y_first, uint32_t block_rows, uint32_t block_stride,
                                   uint32_t n_blocks, uint64_t seed, void* d_rgb_linear_out, void* d_rgba8_out,
@@ -225,6 +246,10 @@ typedef struct rtmi_launch_info {
                              * chains instead (their chain slots could not be allocated or passed the buffer cap): same image */
     uint32_t lds_top_nodes; /* HBM-resident trees: breadth-first nodes of the top of the tree staged into LDS by every workgroup */
     uint32_t pad_mode;      /* what rtmi_tuning::pad_mode resolved to: 1 class pad, 2 bounded by the segment's reach (0: no BVH) */
+    /* ---- added in 0.5: what the most recent call on the scene did ---- */
+    uint32_t bands;         /* bands of rows it was rendered in (0: no call yet) */
+    uint32_t tile_order;    /* 1: its tiles were handed out costliest first, 0: row by row */
+    uint32_t probe_us;      /* duration of the scene's cost probe launch in microseconds (0: none was made) */
 } rtmi_launch_info;
 int rtmi_scene_get_launch_info(const rtmi_scene* scene, rtmi_launch_info* out);
 /* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), rmax^2}. */
@@ -240,9 +265,9 @@ int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf
 int rtmi_bvh_build_passes(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, uint32_t bvh_passes,
                           rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref,
                           uint32_t* depth, float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor);
-/* duration in milliseconds of the most recent TRACE kernel of this scene (the ordered resolve pass that follows it is
- * not included), from HIP events recorded on the launch stream; blocks until that launch has finished.  Used by
- * bench.py for the roofline line. */
+/* Milliseconds the TRACE kernels of the most recent call on this scene took (the bands of a banded call added up; the
+ * ordered resolve passes between them are not included), from HIP events recorded on the launch stream; blocks until that
+ * call has finished.  Used by bench.py for the roofline line. */
 int rtmi_scene_last_kernel_ms(rtmi_scene* scene, float* ms_out);
 
 /* ---- one frame on several GPUs of one node (replaces the worker fan-out of RayTracer::create, main.cc:586-731,

@@ -80,7 +80,8 @@ class Tuning(C.Structure):  # rtmi_tuning: scheduling knobs, 0 = default; none o
                 ("wait_thresh", C.c_uint32), ("pad_mode", C.c_uint32), ("chunk_samples", C.c_int32),
                 ("chain_mode", C.c_int32), ("bvh_passes", C.c_uint32), ("sample_buf_mb", C.c_uint32),
                 ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("kernel", C.c_uint32),
-                ("reserved3", C.c_uint32 * 3), ("lds_top_nodes", C.c_uint32)]
+                ("reserved3", C.c_uint32 * 3), ("lds_top_nodes", C.c_uint32), ("tile_order", C.c_uint32),
+                ("bands", C.c_uint32)]
 
 
 class SceneOptions(C.Structure):
@@ -91,7 +92,8 @@ class SceneOptions(C.Structure):
 class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("struct_size", "kernel", "block_lanes", "grid_blocks", "blocks_per_cu",
                                           "lds_bytes", "scene_in_lds", "stack_depth", "whole_pixel_fallbacks",
-                                          "packed_chains", "packed_chain_fallbacks", "lds_top_nodes", "pad_mode")]
+                                          "packed_chains", "packed_chain_fallbacks", "lds_top_nodes", "pad_mode",
+                                          "bands", "tile_order", "probe_us")]
 
 
 class FrameTiming(C.Structure):
@@ -134,7 +136,8 @@ assert OBJECT_DTYPE.itemsize == 24 and MATERIAL_DTYPE.itemsize == 20 and BVH_NOD
 
 # every symbol include/rtmi.h declares
 EXPORTS = ("rtmi_camera_setup", "rtmi_make_world_spheres", "rtmi_scene_create", "rtmi_scene_destroy",
-           "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_last_error", "rtmi_version",
+           "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_render_rect", "rtmi_render_rect_device",
+           "rtmi_last_error", "rtmi_version",
            "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_launch_info", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
            "rtmi_bvh_build", "rtmi_bvh_build_passes", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
            "rtmi_frame_render_device", "rtmi_frame_get_timing", "rtmi_frame_rccl_ranks", "rtmi_frame_get_scene")
@@ -168,6 +171,9 @@ def lib():
     L.rtmi_render_rows.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]
     L.rtmi_render_row_blocks_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp,
                                                 vp, vp]
+    if hasattr(L, "rtmi_render_rect"):  # (absent from older builds that tools/ A/B against the current one)
+        L.rtmi_render_rect.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]
+        L.rtmi_render_rect_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp]
     L.rtmi_last_error.restype = C.c_char_p
     L.rtmi_version.restype = C.c_char_p
     L.rtmi_scene_get_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
@@ -312,6 +318,20 @@ class Scene:
         _check(lib().rtmi_render_rows(self._h, y0, y1, seed, _ptr(rgb_a) if n else None,
                                       _ptr(rgba_a) if n else None))
         return rgb_a, rgba_a
+
+    def render_rect(self, x0, y0, x1, y1, seed, rgb=True, rgba=True):
+        """rtmi_render_rect: pixels [x0, x1) x [y0, y1) into dense host buffers, blocking."""
+        h, w = max(0, y1 - y0), max(0, x1 - x0)
+        rgb_a = np.zeros((h, w, 3), np.float32) if rgb else None
+        rgba_a = np.zeros((h, w), np.uint32) if rgba else None
+        _check(lib().rtmi_render_rect(self._h, x0, y0, x1, y1, seed, _ptr(rgb_a) if h * w else None,
+                                      _ptr(rgba_a) if h * w else None))
+        return rgb_a, rgba_a
+
+    def render_rect_device(self, x0, y0, x1, y1, seed, d_rgb=0, d_rgba=0, stream=0):
+        """rtmi_render_rect_device: raw device pointers (ints), asynchronous on `stream`."""
+        _check(lib().rtmi_render_rect_device(self._h, x0, y0, x1, y1, seed, C.c_void_p(d_rgb or None),
+                                             C.c_void_p(d_rgba or None), C.c_void_p(stream or None)))
 
     def render_row_blocks_device(self, y_first, block_rows, block_stride, n_blocks, seed, d_rgb=0, d_rgba=0,
                                  stream=0):

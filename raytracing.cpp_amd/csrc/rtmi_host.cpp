@@ -71,7 +71,7 @@ using namespace rtmi;
 
 extern "C" const char* rtmi_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* rtmi_version(void) {
-    return "rtmi 0.4 (gfx950)";
+    return "rtmi 0.5 (gfx950)";
 }
 
 // RayTracingCore::default_setup camera block, reference core.cc:171-216.

@@ -49,9 +49,18 @@ struct RtmiLaunch {
     uint32_t lds_top_nodes;   // HBM-resident trees: this many breadth-first nodes (48-byte records) start the LDS segment
     // image rows handled by this launch
     uint32_t y_first, block_rows, block_stride, n_local_rows;
+    uint32_t x_first, x_end, local_w; // columns [x_first, x_end) of every row (rtmi_render_rect; whole rows: 0, W, W); local_w = x_end - x_first
     uint32_t tiles_x, tiles_y, n_work; // work index space = tiles * 64
     FastDiv div_tiles_x, div_chunks, div_block_rows;
     uint32_t top_down;
+    // the order the 8x8 tiles of this launch are handed out in: tile_order[k] = local tile (ty * tiles_x + tx) of hand-out
+    // position k, the costliest first (host: order_for(), from the per-tile segment counts of a probe launch); NULL: row by
+    // row, bottom rows first.  Scheduling only: the draw streams are keyed by the absolute pixel.
+    const uint32_t* tile_order;
+    // probe launches (STATS variants only): segments per 8x8 tile of the WHOLE image, tile = (gy / 8) * gtiles_x + px / 8
+    uint32_t* tile_cost;
+    uint32_t gtiles_x;
+    unsigned long long* tail_probe; // -DRTMI_TAILPROBE builds only: per wave {start, first refill past the end, exit} in 100 MHz ticks
     // sample-chunk split: a work item is `chunk` consecutive samples of one pixel; their colours go to sample_buf
     // ([pixel][sample] float4) and rtmi_resolve_kernel adds them up in sample order.  n_chunks == 1: a lane owns
     // the whole pixel and sums in registers.

@@ -574,16 +574,15 @@ struct RayTracingCore {
         return rtmi_render_rows(rts_gpu_scene.get(), y0, y1, seed, rgb_linear, reinterpret_cast<uint32_t*>(rgba));
     }
 
-    // One RayTracingWorkPackage{start, end} (main.cc:404-407): renders the rows the tile spans and copies out the
-    // tile's pixels, row-major, (ex-sx)*(ey-sy) RGBAColor.
-    int raytrace_tile(uint16_t sx, uint16_t sy, uint16_t ex, uint16_t ey, uint64_t seed, RGBAColor* tile_out) const {
+    // One RayTracingWorkPackage{start, end} (main.cc:404-407) through the tile-granular entry (rtmi_render_rect, 0.5): the
+    // tile's pixels and nothing else, row-major, (ex-sx)*(ey-sy) RGBAColor.  (Rounds 1-4 rendered every column of the tile's
+    // rows and threw all but the tile away: 240 times the work for the reference's 8x8 package at 1920 wide.)  Correct for a
+    // host that keeps the reference's queue of 8x8 packages unchanged, and slow -- a launch, a resolve pass and a copy per 64
+    // pixels; raytrace_rows is the fast granularity.
+    int raytrace_tile(uint16_t sx, uint16_t sy, uint16_t ex, uint16_t ey, uint64_t seed, RGBAColor* tile_out,
+                      float* rgb_linear = nullptr) const noexcept {
         if (ex < sx || ey < sy || ex > rts_img_width || ey > rts_img_height) return RTMI_ERR_BAD_ARG;
-        std::vector<RGBAColor> rows(size_t(ey - sy) * rts_img_width);
-        const int rc = raytrace_rows(sy, ey, seed, rows.data());
-        if (rc != RTMI_OK) return rc;
-        for (uint32_t y = 0; y < uint32_t(ey - sy); ++y)
-            std::memcpy(tile_out + size_t(y) * (ex - sx), rows.data() + size_t(y) * rts_img_width + sx, size_t(ex - sx) * sizeof(RGBAColor));
-        return RTMI_OK;
+        return rtmi_render_rect(rts_gpu_scene.get(), sx, sy, ex, ey, seed, rgb_linear, reinterpret_cast<uint32_t*>(tile_out));
     }
 };
 

@@ -104,3 +104,40 @@ def big_grid(n_side=316, seed=4):
                defocus_angle=0.6, focus_distance=10.0 * scale, lookfrom=(13.0 * scale, 2.0 * scale, 3.0 * scale),
                lookat=(0.0, 0.0, 0.0), world_up=(0.0, 1.0, 0.0))
     return objs, mats, cam
+
+
+def fuzz_world(rng, case):
+    """One random world of the differential fuzz (tools/fuzz_vs_oracle.py, tests/test_gpu_parity.py): 1-90 spheres -- every
+    fourth world 100-600 spheres over a field hundreds of radii wide, where the reach-bounded box pad is the library's choice --
+    negative radii, scales 1e-2 .. 1e3, all three materials, bounce limits 1-120, defocus on and off, half of the worlds over a
+    huge ground sphere.  Returns (objs, mats, camera kwargs); `rng` is a numpy Generator, `case` selects the wide worlds."""
+    wide = case % 4 == 3
+    n = int(rng.integers(100, 600)) if wide else int(rng.integers(1, 90))
+    n_mats = int(rng.integers(1, n + 1))
+    objs = np.zeros(n, OBJECT_DTYPE)
+    mats = np.zeros(n_mats, MATERIAL_DTYPE)
+    scale = float(10.0 ** rng.uniform(-2, 3))
+    for m in range(n_mats):
+        k = int(rng.integers(0, 3))
+        if k == 0:
+            mats[m] = (0, (*rng.uniform(0.0, 1.2, 3), 0.0))
+        elif k == 1:
+            mats[m] = (1, (*rng.uniform(0.3, 1.0, 3), float(rng.uniform(0.0, 1.5))))
+        else:
+            mats[m] = (2, (float(rng.uniform(0.6, 2.2)), 0, 0, 0))
+    objs["center"] = (rng.normal(0, 3.0, (n, 3)) * scale).astype(np.float32)
+    objs["radius"] = (10.0 ** rng.uniform(-1.5, 0.8, n) * scale * rng.choice([1.0, 1.0, 1.0, -1.0], n)).astype(np.float32)
+    if wide:  # a field hundreds of radii wide, flat or not
+        objs["center"] = (rng.uniform(-1.0, 1.0, (n, 3)) * (float(rng.uniform(30, 300)), float(rng.choice([0.5, 30.0])),
+                                                           float(rng.uniform(30, 300))) * scale).astype(np.float32)
+        objs["radius"] = (10.0 ** rng.uniform(-1.0, 0.0, n) * scale).astype(np.float32)
+    objs["material"] = rng.integers(0, n_mats, n)
+    if rng.random() < 0.5:
+        objs["center"][0] = (0, -1000.0 * scale - scale, 0)
+        objs["radius"][0] = 1000.0 * scale
+    depth = int(rng.choice([1, 3, 8, 20, 50, 120]))
+    lf = tuple(float(v) for v in rng.normal(0, 6.0, 3) * scale)
+    kw = dict(aspect_ratio=1.0, image_width=int(rng.choice([17, 32, 40])), samples_per_pixel=int(rng.choice([1, 4, 9])),
+              max_depth=depth, vertical_fov=float(rng.uniform(20, 90)), defocus_angle=float(rng.choice([0.0, 0.5, 3.0])),
+              focus_distance=float(5 * scale), lookfrom=lf, lookat=(0.0, 0.0, 0.0), world_up=(0.0, 1.0, 0.0))
+    return objs, mats, kw

@@ -760,6 +760,135 @@ def test_frames_larger_than_the_sample_buffer_are_rendered_in_bands(pkg, ob, rto
     _assert_frames_equal(frame, want)
 
 
+def test_render_rect_tiles_the_frame(pkg, ob, rtow, gpu):
+    """rtmi_render_rect / rtmi_render_rect_device (0.5): the reference's seam is a tile, RayTracingWorkPackage{start, end}
+    (main.cc:404-407, consumed pixel by pixel at :507-519).  A frame rendered as shuffled 8x8 packages -- the reference's own
+    queue, main.cc:615-633 -- and as 64x16 tiles equals rtmi_render_rows and the oracle bit for bit (the draw streams are keyed
+    by the absolute pixel), on both accel paths, both memory layouts, both chain forms; clipped tiles at the right and bottom
+    edges (120 x 67 is a multiple of neither tile size); the error paths."""
+    torch = gpu
+    rng = np.random.default_rng(5)
+    for kw, accel, tun in ((dict(image_width=120, samples_per_pixel=12, max_depth=50), pkg.ACCEL_BVH, None),
+                           (dict(image_width=120, samples_per_pixel=12, max_depth=12), pkg.ACCEL_BRUTE, None),  # packed chains
+                           (dict(image_width=120, samples_per_pixel=3, max_depth=50), pkg.ACCEL_BVH, dict(force_hbm_scene=1))):  # whole-pixel items
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        W, H = cam.img_width, cam.img_height
+        want, want8 = ob.render_rect_counter(ocam, *rtow, 77, 0, 0, W, H, nthreads=8)
+        with pkg.Scene(cam, *rtow, accel=accel, tuning=tun) as s:
+            rows, rows8 = s.render_rows(0, H, 77)
+            _assert_frames_equal(rows, want)
+            assert np.array_equal(rows8, want8)
+            for tw, th in ((8, 8), (64, 16)):
+                tiles = [(x, y) for y in range(0, H, th) for x in range(0, W, tw)]
+                rng.shuffle(tiles)
+                got, got8 = np.zeros_like(rows), np.zeros_like(rows8)
+                for x, y in tiles:
+                    x1, y1 = min(W, x + tw), min(H, y + th)
+                    t, t8 = s.render_rect(x, y, x1, y1, 77)
+                    assert t.shape == (y1 - y, x1 - x, 3) and t8.shape == (y1 - y, x1 - x)
+                    got[y:y1, x:x1], got8[y:y1, x:x1] = t, t8
+                _assert_frames_equal(got, rows)
+                assert np.array_equal(got8, rows8)
+            # either output alone, an empty rectangle, a one-pixel one
+            only8 = s.render_rect(3, 5, 40, 21, 77, rgb=False)[1]
+            assert np.array_equal(only8, rows8[5:21, 3:40])
+            e, e8 = s.render_rect(9, 9, 9, 30, 77)
+            assert e.shape == (21, 0, 3) and e8.shape == (21, 0)
+            one, _ = s.render_rect(W - 1, H - 1, W, H, 77)
+            _assert_frames_equal(one, rows[H - 1:, W - 1:])
+            # device-pointer form, asynchronous on the caller's stream
+            dev = torch.device("cuda", 0)
+            buf = torch.zeros((30, 50, 3), dtype=torch.float32, device=dev)
+            buf8 = torch.zeros((30, 50), dtype=torch.int32, device=dev)
+            s.render_rect_device(33, 20, 83, 50, 77, buf.data_ptr(), buf8.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            torch.cuda.synchronize()
+            _assert_frames_equal(buf.cpu().numpy(), rows[20:50, 33:83])
+            assert np.array_equal(buf8.cpu().numpy().view(np.uint32), rows8[20:50, 33:83])
+            for bad in ((0, 0, W + 1, 8), (0, 0, 8, H + 1), (9, 0, 8, 8), (0, 9, 8, 8)):
+                with pytest.raises(pkg.RtmiError) as err:
+                    s.render_rect(*bad, 77)
+                assert err.value.code == pkg.RTMI_ERR_BAD_ARG
+
+
+def test_cost_ordered_tiles_and_overlapped_bands_do_not_change_the_image(pkg, ob, rtow, gpu):
+    """Round 5 scheduling: the 8x8 tiles of a launch handed out costliest first (per-tile segment counts from one probe launch
+    per scene), and a call rendered in bands of rows that alternate between two streams of the library so that a band's
+    ordered resolve pass and tail run beside the next band's trace kernel.  Neither changes a bit: whole frames, row ranges that
+    do not start on a tile row, sharded row blocks, rectangles, both accel paths, packed and run-length chains; the launch
+    report says what the most recent call did; back-to-back asynchronous calls on one stream stay ordered."""
+    torch = gpu
+    kw = dict(image_width=160, samples_per_pixel=24, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    W, H = cam.img_width, cam.img_height
+    want, want8 = ob.render_rect_counter(ocam, *rtow, 46, 0, 0, W, H, nthreads=8)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for accel, _ in _both(pkg):
+        for tun in (dict(tile_order=2), dict(tile_order=2, bands=4), dict(tile_order=1, bands=3, chunk_samples=5),
+                    dict(tile_order=2, bands=2, force_hbm_scene=1), dict(tile_order=2, bands=5, chain_mode=1, block_lanes=512),
+                    dict(tile_order=2, chunk_samples=7, bands=2)):
+            with pkg.Scene(cam, *rtow, accel=accel, tuning=tun) as s:
+                assert s.launch_info()["bands"] == 0
+                rgb, rgba = s.render_rows(0, H, 46)
+                li = s.launch_info()
+                assert li["bands"] == min(tun.get("bands", 1), 4) and li["tile_order"] == (1 if tun["tile_order"] == 2 else 0), (tun, li)
+                assert (li["probe_us"] > 0) == (tun["tile_order"] == 2)
+                assert s.last_kernel_ms() > 0.0
+                _assert_frames_equal(rgb, want)
+                assert np.array_equal(rgba, want8)
+                part, part8 = s.render_rows(5, 77, 46)  # bands of whole tile rows from a row that is not a multiple of 8
+                _assert_frames_equal(part, want[5:77])
+                assert np.array_equal(part8, want8[5:77])
+                rect, _ = s.render_rect(13, 3, 150, 88, 46)
+                _assert_frames_equal(rect, want[3:88, 13:150])
+                # three ranks' worth of interleaved row blocks, launched back to back on one stream without a host sync in between
+                plan = pkg.RowShardPlan(H, 8, 3)
+                parts = [torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev) for _ in range(3)]
+                for r in range(3):
+                    y_first, n_blocks, _rows = plan.shard(r)
+                    s.render_row_blocks_device(y_first, 8, 3, n_blocks, 46, parts[r].data_ptr(), 0, stream)
+                torch.cuda.synchronize()
+                frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev)).cpu().numpy()
+                _assert_frames_equal(frame, want)
+    # the box of config 5 (packed chains multiplied by the resolve pass) in overlapped bands
+    g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
+    ccam = pkg.camera_setup(pkg.camera_params(**json.loads(str(g["camera"]))))
+    with pkg.Scene(ccam, g["objects"], g["materials"], tuning=dict(tile_order=2, bands=6)) as s:
+        rgb, rgba = s.render_rows(0, ccam.img_height, int(g["seed"]))
+        assert s.launch_info()["bands"] == 6 and s.launch_info()["packed_chains"] > 0
+    _assert_frames_equal(rgb, g["rgb"])
+    assert np.array_equal(rgba, g["rgba"])
+    with pytest.raises(pkg.RtmiError) as err:
+        pkg.Scene(cam, *rtow, tuning=dict(tile_order=3))
+    assert err.value.code == pkg.RTMI_ERR_BAD_ARG
+
+
+def test_differential_fuzz_slice(pkg, ob, gpu):
+    """A slice of tools/fuzz_vs_oracle.py where the driver runs it (the round-4 log of 9 800 worlds is
+    profiles/r04_fuzz_vs_oracle.txt): 200 random worlds -- 1-90 spheres, every fourth 100-600 spheres over a field hundreds of
+    radii wide; negative radii, scales 1e-2 .. 1e3, bounce limits up to 120 -- through the walk x {LDS, HBM with the top of the
+    tree staged / not staged, either pad rule, run-length chains, whole-pixel items, cost-ordered tiles in overlapped bands}
+    and the scan x 4 variants, every float against the oracle (NaN = NaN)."""
+    rng = np.random.default_rng(505)
+    bad = []
+    for case in range(200):
+        objs, mats, kw = pkg.workloads.fuzz_world(rng, case)
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        want, want8 = ob.render_rect_counter(ocam, objs, mats, case, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)
+        for accel in (pkg.ACCEL_BVH, pkg.ACCEL_BRUTE):
+            tunings = (None, dict(force_hbm_scene=1, chain_mode=1), dict(chunk_samples=-1), dict(tile_order=2, bands=3, chunk_samples=2))
+            if accel == pkg.ACCEL_BVH:  # (two of the four walk-only variants per world)
+                tunings += ((dict(pad_mode=2), dict(pad_mode=1, force_hbm_scene=1, lds_top_nodes=10, bvh_passes=9)) if case % 2 else
+                            (dict(pad_mode=1, bvh_passes=1), dict(pad_mode=2, force_hbm_scene=1, lds_top_nodes=1)))
+            for tun in tunings:
+                with pkg.Scene(cam, objs, mats, accel=accel, tuning=tun) as s:
+                    rgb, rgba = s.render_rows(0, cam.img_height, case)
+                same = (rgb.view(np.uint32) == want.view(np.uint32)) | (np.isnan(rgb) & np.isnan(want))
+                if not same.all() or not np.array_equal(rgba, want8):
+                    bad.append((case, accel, tun, int((~same).any(-1).sum())))
+    assert not bad, bad[:10]
+
+
 @pytest.mark.parametrize("name", ["thumb_config2", "thumb_config5"])
 def test_regression_thumbnails(pkg, gpu, name):
     """The stored regression images (tests/golden/thumb_*.png, written by the oracle) against the GPU's RGBA8 output."""
@@ -976,8 +1105,9 @@ def _decades_world(pkg, seed, m=200):
 def test_bvh_walk_equals_linear_scan_on_generated_worlds(pkg, gpu):
     """The exactness claim of the BVH: for 36 generated worlds -- the reference's generator under other seeds,
     random spheres of mixed radii, jittered grids over an R = 1e4 ground, radii over seven decades seen from 20 to 30 000
-    units away -- the walk and the linear scan give bit-identical frames, with the tree in LDS (64-byte nodes, where the
-    scene fits) and forced to stay in HBM (48-byte nodes with fp16 half extents)."""
+    units away -- the walk and the linear scan give bit-identical frames, with the tree in LDS (where the scene fits) and forced
+    to stay in HBM -- the same 48-byte node records with fp16 half extents in both layouts, read by walk_nodes_lds and
+    walk_nodes_hbm."""
     bad = {}
     for i in range(36):
         if i % 3 == 0:
@@ -1086,9 +1216,10 @@ def test_config4_full_size(pkg, ob, gpu):
 def test_config5_full_size(pkg, ob, gpu):
     """BASELINE configs[4] at its own size: 800x800, 4096 spp, 200 bounces, rendered the way the library and bench.py do by
     default (RTMI_ACCEL_AUTO: the linear scan for a 7-sphere scene, packed attenuation chains multiplied by the resolve pass) and
-    with the BVH walk.  The 42 GB of sample records + 210 GB of chain slots exceed the library's 24 GB buffer cap, so the call
-    runs in bands of rows without any override (ten with the chain slots); both renders give the same bits, a row range rendered
-    on its own (one band, straddling a band boundary of the full call) gives the same bits, and 16 pixels equal the oracle."""
+    with the BVH walk.  The 42 GB of sample records + 210 GB of chain slots exceed the library's buffer cap (a third of the
+    device's memory: 96 GB on MI355X), so the call runs in bands of rows without any override (three); both renders give the same
+    bits, a row range rendered on its own (one band, straddling a band boundary of the full call) gives the same bits, and 16
+    pixels equal the oracle."""
     objs, mats, kw = cornell_like()
     cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
     assert (cam.img_width, cam.img_height, cam.samples_per_pixel, cam.maxdepth) == (800, 800, 4096, 200)
@@ -1099,11 +1230,10 @@ def test_config5_full_size(pkg, ob, gpu):
         rgb, rgba = s.render_rows(0, 800, 55)
         assert s.last_kernel_ms() > 500.0
         assert s.launch_info()["packed_chain_fallbacks"] == 0 and s.launch_info()["whole_pixel_fallbacks"] == 0
-        # rows per band of the full call: 24 GB / (800 px x 4096 spp x (16 B record + chain slot))
-        per_row = 800 * 4096 * (16 + 4 * li["packed_chains"])
-        n_bands = -(-800 // ((24 << 30) // per_row))
-        band = -(-800 // n_bands)
-        assert n_bands >= 8
+        # the full call ran in bands of whole tile rows, as many as the cap (a third of the device's memory) asks for
+        n_bands = s.launch_info()["bands"]
+        assert 2 <= n_bands <= 12
+        band = -(-100 // n_bands) * 8
         part, part8 = s.render_rows(band - 8, band + 8, 55)  # straddles the first band boundary of the full call
     assert rgb[band - 8:band + 8].tobytes() == part.tobytes() and np.array_equal(rgba[band - 8:band + 8], part8)
     with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as s:
