@@ -440,10 +440,20 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             const uint4 r0 = lds_spheres[first + q];
             const uint4 r1 = lds_spheres[first + q + (two ? 1u : 0u)];
             float h0, h1, d0, d1;
-            sphere_delta(r0, t, h0, d0);
-            sphere_delta(r1, t, h1, d1);
-            if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, ra, first + q, lds_aux, t.tbest, t.best);
-            if (two & (d1 >= 0.0f)) sphere_root_bvh(h1, d1, t, ra, first + q + 1u, lds_aux, t.tbest, t.best);
+            bool k0, k1;
+            sphere_delta_cand(r0, t, h0, d0, k0);
+            sphere_delta_cand(r1, t, h1, d1, k1);
+            k1 = k1 & two;
+            // Roots only for spheres that can have one ahead of the origin (sphere_delta_cand), and ONE pass of the root
+            // arithmetic for the lanes' first such sphere, whichever of the two it is: with a separate branch per sphere the wave
+            // ran both (~45 instructions each) whenever any lane needed either -- nearly every leaf trip -- although hardly a lane
+            // needs both; the second pass is left for the trips in which one does.  Per lane the spheres are still taken in slot
+            // order (and ties go by object index, sphere_root_bvh): the closest hit is the same.
+            if (k0 | k1) {
+                const bool sec = !k0;
+                sphere_root_bvh(sec ? h1 : h0, sec ? d1 : d0, t, ra, first + q + (sec ? 1u : 0u), lds_aux, t.tbest, t.best);
+                if (k0 & k1) sphere_root_bvh(h1, d1, t, ra, first + q + 1u, lds_aux, t.tbest, t.best);
+            }
         };
         pair(0u);
         if (cnt > 2u) {
@@ -473,8 +483,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                 if (cnt == 1u) { // a lone sphere (the ground): one discriminant, not the pair routine's two
                     const uint32_t slot = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
                     float h0, d0;
-                    sphere_delta(lds_spheres[slot], t, h0, d0);
-                    if (d0 >= 0.0f) sphere_root_bvh(h0, d0, t, recip_for(t.a), slot, lds_aux, t.tbest, t.best);
+                    bool k0;
+                    sphere_delta_cand(lds_spheres[slot], t, h0, d0, k0);
+                    if (k0) sphere_root_bvh(h0, d0, t, recip_for(t.a), slot, lds_aux, t.tbest, t.best);
                     if (STATS) st_sphere += 1u;
                 } else {
                     test_leaf(ref);

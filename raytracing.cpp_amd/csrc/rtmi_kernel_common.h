@@ -474,6 +474,21 @@ DEV void sphere_delta(const uint4 raw, const Trav& t, float& h, float& delta) {
     const float c = vdot(oc, oc) - __uint_as_float(raw.w);
     delta = h * h - t.a * c;
 }
+// The same, and whether the sphere needs its roots at all: `cand` = the discriminant is not negative AND the sphere is not
+// wholly behind the origin.  A sphere with h < 0 (centre behind the origin along the ray) and c > 0 (origin outside it) is met by
+// the ray's LINE only at negative parameters, and the reference's fp32 arithmetic agrees: fl(a c) >= 0 (a = dot(d, d) >= 0, c > 0),
+// so delta = fl(fl(h h) - fl(a c)) <= fl(h h), sqrt is monotone and sqrt(fl(h h)) rounds to |h| (the relative error of fl(h h) is at
+// most 2^-24, halved by the root: less than half an ulp of |h|), hence sqrtd <= |h| and both numerators h - sqrtd, h + sqrtd are <= 0:
+// neither root passes `root > 0.0001` (object.defs.cc:52-57) -- skipping the square root and the divisions changes no bit.  (A NaN
+// in h or c compares false and takes the full path.)  Half of the spheres whose line a ray crosses are behind it; a ray that
+// leaves a sphere has that sphere's own centre behind it, and its origin outside it half of the time.
+DEV void sphere_delta_cand(const uint4 raw, const Trav& t, float& h, float& delta, bool& cand) {
+    const V3 oc = mk(__uint_as_float(raw.x) - t.o.x, __uint_as_float(raw.y) - t.o.y, __uint_as_float(raw.z) - t.o.z);
+    h = vdot(t.d, oc);
+    const float c = vdot(oc, oc) - __uint_as_float(raw.w);
+    delta = h * h - t.a * c;
+    cand = (delta >= 0.0f) & !((h < 0.0f) & (c > 0.0f));
+}
 DEV void sphere_root(float h, float delta, const Trav& t, const Recip& ra, uint32_t slot, float& tbest, uint32_t& best) {
     // the in-range cores of the square-root and division expansions on a reciprocal shared by the segment's roots (as in
     // the walk, below): inside the box of config 5 every ray's line meets four or five of the seven spheres, and the full
