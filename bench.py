@@ -34,6 +34,7 @@ import os
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import argparse  # noqa: E402
+import re  # noqa: E402
 import json  # noqa: E402
 import socket  # noqa: E402
 import subprocess  # noqa: E402
@@ -192,7 +193,9 @@ def measure_traffic(args):
                 return None, f"rocprofv3 --pmc {counter} failed (exit {p.returncode})"
             total, n = 0.0, 0
             for row in csv.DictReader(open(files[0])):
-                if "rtmi_trace_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                # (the timed variants only: the scene's one cost probe launch in the first frame is the counting variant,
+                # rtmi_trace_kernel<accel, true, ...>)
+                if re.search(r"rtmi_trace_kernel<\d+, false,", row.get("Kernel_Name", "")) and row.get("Counter_Name") == counter:
                     total += float(row["Counter_Value"])
                     n += 1
             if n == 0 or n % 2:

@@ -45,12 +45,15 @@ class WorldDef(C.Structure):  # src/ray.tracer.core.cc:67-95
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "sphere_tests", "node_tests", "rng_doubles",
-                                          "hit_lambertian", "hit_metallic", "hit_dielectric", "end_sky",
-                                          "end_depth", "end_absorbed")]
+    _fields_ = ([(n, C.c_uint64) for n in ("samples", "segments", "sphere_tests", "node_tests", "rng_doubles",
+                                           "hit_lambertian", "hit_metallic", "hit_dielectric", "end_sky",
+                                           "end_depth", "end_absorbed")]
+                # instrumented BVH walk only (tools/descent_score.py): by where a segment starts -- camera, peeled sphere, tree sphere
+                + [(n, C.c_uint64 * 3) for n in ("seg_class", "trips_class", "leaf_trips_class")]
+                + [(n, C.c_uint64) for n in ("descent_levels", "descent_sibling_hits")])
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        return {n: (int(getattr(self, n)) if t is C.c_uint64 else [int(v) for v in getattr(self, n)]) for n, t in self._fields_}
 
 
 OBJECT_DTYPE = np.dtype([("kind", "<u4"), ("center", "<f4", 3), ("radius", "<f4"), ("material", "<u4")])  # 24 B
@@ -211,6 +214,13 @@ def render_pixels_mt(cam, objs, mats, mt_seed, xy, counters=False):
                                     _ptr(rgb), _ptr(rgba), C.byref(ctr) if counters else None)
     assert rc == 0
     return (rgb, rgba, ctr.as_dict()) if counters else (rgb, rgba)
+
+
+def set_sibling_start(on):
+    """orc_set_sibling_start: the instrumented walk starts in the origin sphere's own leaf (what the library does for trees in HBM)."""
+    lib().orc_set_sibling_start.argtypes = [C.c_int]
+    lib().orc_set_sibling_start.restype = None
+    lib().orc_set_sibling_start(int(bool(on)))
 
 
 def render_rect_counter(cam, objs, mats, seed, x0, y0, x1, y1, nthreads=1, counters=False, bvh=None):

@@ -599,6 +599,28 @@ static inline float ray_pad(const scene_t* sc, const ray_t* r, const float inv[3
     return e;
 }
 
+/* the object the current segment starts on, ~0u for a camera ray: for the walk's counters, and for the walk that starts in the
+ * origin sphere's own leaf (orc_set_sibling_start) -- never for the image, which does not depend on the visiting order */
+static __thread uint32_t g_origin_obj = 0xffffffffu;
+/* 1: a segment that starts on a sphere of the tree tests the siblings along the way down to that sphere's leaf (one box test per
+ * level) and starts its walk in that leaf, as the library does for trees that stay in HBM (rtmi_tuning::sibling_lists,
+ * csrc/rtmi_device.hip begin_segment): the instrumented walk then counts the box tests that kernel makes */
+static int g_sibling_start = 0;
+void orc_set_sibling_start(int on) { g_sibling_start = on; }
+static int path_to_slot(const scene_t* sc, uint32_t ref, uint32_t slot, uint32_t* path, int depth) {
+    if (ref & 0x80000000u) {
+        const uint32_t first = ref & 0x00ffffffu, count = (ref >> 24) & 0x7fu;
+        return (slot >= first && slot < first + count) ? depth : -1;
+    }
+    if (depth >= 64) return -1;
+    path[depth] = ref;
+    for (int k = 0; k < 2; ++k) {
+        const int d = path_to_slot(sc, sc->nodes[ref].child[k], slot, path, depth + 1);
+        if (d >= 0) return d;
+    }
+    return -1;
+}
+
 static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec* rec, uint32_t* index,
                           orc_counters* ctr) {
     const float inv[3] = {1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z};
@@ -651,8 +673,52 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
     /* the pad of this segment's boxes, with the far limit the peeled leaves left */
     const float pad = ray_pad(sc, r, inv, oinv, best_t);
     for (int i = 0; i < 3; ++i) pinv[i] = pad * ainv[i];
+    /* (counters) class of the segment and, for one that starts on a sphere inside the tree, the nodes above that sphere's leaf */
+    int cls = 0, path_len = -1;
+    uint32_t path[64];
+    uint32_t origin_slot = 0xffffffffu;
+    if (ctr || g_sibling_start) {
+        if (g_origin_obj != 0xffffffffu) {
+            cls = 1;
+            uint32_t slot = 0xffffffffu;
+            for (uint32_t q = 0; q < sc->n_slots; ++q)
+                if (sc->slots[q] == g_origin_obj) { slot = q; break; }
+            if (slot != 0xffffffffu && !no_walk) {
+                path_len = path_to_slot(sc, cur, slot, path, 0);
+                if (path_len >= 0) cls = 2;
+                origin_slot = slot;
+            }
+        }
+        if (ctr) ctr->seg_class[cls]++;
+    }
+    if (g_sibling_start && path_len >= 0) {
+        /* the siblings along the way, root-most first (the deepest ends on top of the stack), each pruned by the padded slab test of
+         * the node step; then the walk starts in the origin's own leaf */
+        for (int q = 0; q < path_len; ++q) {
+            const orc_bvh_node* nd = &sc->nodes[path[q]];
+            int on;
+            if (q + 1 < path_len) on = nd->child[0] == path[q + 1] ? 0 : 1;
+            else {
+                const uint32_t c0 = nd->child[0];
+                on = ((c0 & 0x80000000u) && origin_slot >= (c0 & 0x00ffffffu) && origin_slot < (c0 & 0x00ffffffu) + ((c0 >> 24) & 0x7fu)) ? 0 : 1;
+            }
+            const int k = 1 - on;
+            float nmax = tmin, fmin_ = best_t;
+            for (int i = 0; i < 3; ++i) {
+                const float tc = fmaf(nd->ctr[k][i], inv[i], oinv[i]);
+                const float th = fmaf(nd->half[k][i], ainv[i], pinv[i]);
+                nmax = fmaxf(nmax, tc - th);
+                fmin_ = fminf(fmin_, tc + th);
+            }
+            if (ctr) ctr->node_tests += 1;
+            if (nmax <= fmin_) stack[sp++] = nd->child[k];
+            if (q + 1 == path_len) cur = nd->child[on];
+        }
+        path_len = -1; /* (the descent counters below describe the walk from the top) */
+    }
     for (; !no_walk;) {
         if (cur & 0x80000000u) {
+            if (ctr) ctr->leaf_trips_class[cls]++;
             const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
             for (uint32_t s = 0; s < count; ++s) {
                 const uint32_t oi = sc->slots[first + s];
@@ -683,6 +749,26 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
         }
         if (ctr) ctr->node_tests += 2;
         const int h0 = tn[0] <= tf[0], h1 = tn[1] <= tf[1];
+        if (ctr) {
+            ctr->trips_class[cls]++;
+            for (int q = 0; q < path_len; ++q) {
+                if (path[q] != cur) continue;
+                /* a node above the origin sphere's leaf: which child leads on, and is the other one's box hit? */
+                const uint32_t on = q + 1 < path_len ? path[q + 1] : 0xffffffffu;
+                const int on_is_0 = q + 1 < path_len ? nd->child[0] == on : -1;
+                int sib_hit;
+                if (on_is_0 >= 0) sib_hit = on_is_0 ? h1 : h0;
+                else { /* the last node of the path: the child that is the origin's leaf */
+                    uint32_t slot = 0;
+                    for (uint32_t z = 0; z < sc->n_slots; ++z) if (sc->slots[z] == g_origin_obj) { slot = z; break; }
+                    const uint32_t c0 = nd->child[0];
+                    const int leaf0 = (c0 & 0x80000000u) && slot >= (c0 & 0x00ffffffu) && slot < (c0 & 0x00ffffffu) + ((c0 >> 24) & 0x7fu);
+                    sib_hit = leaf0 ? h1 : h0;
+                }
+                ctr->descent_levels++;
+                ctr->descent_sibling_hits += (uint64_t)sib_hit;
+            }
+        }
         if (h0 && h1) {
             const int swap = tn[1] < tn[0];
             stack[sp++] = nd->child[swap ? 0 : 1];
@@ -805,8 +891,10 @@ static v3 compute_color(const ray_t* r, uint32_t depth, const scene_t* sc, orc_r
     }
     hit_rec rec;
     if (ctr) ctr->segments++;
-    const int hit = sc->nodes || sc->n_slots ? bvh_intersects(sc, r, 0.0001f, &rec, NULL, ctr)
+    uint32_t hit_index = 0xffffffffu;
+    const int hit = sc->nodes || sc->n_slots ? bvh_intersects(sc, r, 0.0001f, &rec, &hit_index, ctr)
                                              : world_intersects(sc, r, 0.0001, (double)INFINITY, &rec, NULL, ctr);
+    g_origin_obj = hit ? hit_index : 0xffffffffu; /* (counters of the instrumented walk: where the next segment starts) */
     if (hit) {
         const orc_material* m = &sc->mats[rec.material]; /* MaterialCollection::operator[], material.defs.hpp:102 */
         v3 att;
@@ -833,6 +921,7 @@ static void raytrace_pixel(const orc_camera* cam, const scene_t* sc, uint32_t x,
             counter_begin(rng, y * cam->img_width + x, s);
         }
         const ray_t r = get_ray(cam, x, y, rng);
+        g_origin_obj = 0xffffffffu; /* (walk counters: a camera ray) */
         pixel_color = vadd(pixel_color, compute_color(&r, cam->maxdepth, sc, rng, ctr));
         if (ctr) ctr->samples++;
     }
@@ -1109,16 +1198,19 @@ double orc_bench_mt(const orc_camera* cam, const orc_object* objs, uint32_t n_ob
     pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    /* only the workers that started are joined (a thread limit of the cgroup can refuse one: pthread_join on a thread that
+     * was never created is undefined); the packages they leave are rendered by this thread, so every sample is counted */
+    int started = 0;
     for (int t = 0; t < nthreads; ++t) {
         jobs[t].cam = cam; jobs[t].sc = &sc; jobs[t].queue = q; jobs[t].n_pkgs = n_pkgs; jobs[t].next = &next;
         jobs[t].stride = stride; jobs[t].seed = mt_seed + (uint32_t)t; jobs[t].rgba_out = rgba_out;
-        pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
+        if (pthread_create(&th[started], NULL, bench_worker, &jobs[t]) != 0) break;
+        ++started;
     }
+    if (started < nthreads) bench_worker(&jobs[started]); /* (returns when the queue is empty) */
     uint64_t samples = 0;
-    for (int t = 0; t < nthreads; ++t) {
-        pthread_join(th[t], NULL);
-        samples += jobs[t].samples;
-    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    for (int t = 0; t < nthreads; ++t) samples += jobs[t].samples;
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (samples_out) *samples_out = samples;
     free(jobs);

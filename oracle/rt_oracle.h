@@ -88,6 +88,12 @@ typedef struct orc_counters {
     uint64_t rng_doubles;
     uint64_t hit_lambertian, hit_metallic, hit_dielectric;
     uint64_t end_sky, end_depth, end_absorbed;
+    /* instrumented BVH walk only (tools/descent_score.py): segments, node trips and leaf trips by where the segment starts --
+     * [0] the camera, [1] a sphere peeled off the top of the tree (the ground), [2] a sphere inside the tree; for class 2 the
+     * internal nodes on the way from the walk's start to the origin sphere's own leaf (the origin lies inside every one of
+     * those boxes: the descent no tree can avoid) and how many of their sibling boxes the ray hits */
+    uint64_t seg_class[3], trips_class[3], leaf_trips_class[3];
+    uint64_t descent_levels, descent_sibling_hits;
 } orc_counters;
 
 /* flat BVH node used only by the instrumented BVH walk (build-side extension, see rt_oracle.c) */
@@ -159,6 +165,10 @@ int orc_render_rect_counter(const orc_camera* cam, const orc_object* objs, uint3
 /* Instrumented BVH walk (build-side extension): same image as the linear scan, counts node/sphere tests.
  * slots[i] = object index stored at leaf slot i; bounds used for the per-ray pad are in pad_classes
  * (n_classes x 8 floats: lo[3], hi[3], inv2rmin, unused). */
+/* 1: the instrumented walk starts, for a segment that begins on a sphere of the tree, in that sphere's own leaf after testing the
+ * siblings along the way down to it -- what the library does for trees that stay in HBM; 0 (default): every walk from the top */
+void orc_set_sibling_start(int on);
+
 int orc_render_rect_counter_bvh(const orc_camera* cam, const orc_object* objs, uint32_t n_objs,
                                 const orc_material* mats, uint32_t n_mats, const orc_bvh_node* nodes, uint32_t n_nodes,
                                 const uint32_t* slots, uint32_t n_slots, const float* pad_classes, uint32_t n_classes,

@@ -247,7 +247,7 @@ def test_header_is_plain_c_and_every_prototype_is_exported(pkg, tmp_path):
     src = tmp_path / "hc.c"
     src.write_text('#include "rtmi.h"\n'
                    'int main(void) { return (sizeof(rtmi_object) == 24 && sizeof(rtmi_material) == 20 && sizeof(rtmi_camera) == 100\n'
-                   '                         && sizeof(rtmi_bvh_node) == 64 && sizeof(rtmi_launch_info) == 64 && sizeof(rtmi_tuning) == 72) ? 0 : 1; }\n')
+                   '                         && sizeof(rtmi_bvh_node) == 64 && sizeof(rtmi_launch_info) == 68 && sizeof(rtmi_tuning) == 76) ? 0 : 1; }\n')
     exe = tmp_path / "hc"
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)

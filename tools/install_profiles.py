@@ -25,6 +25,8 @@ for cfg in sys.argv[4:]:
         if not m:
             continue
         k = m.group(1)
+        if re.search(r"rtmi_trace_kernel<\d+, true,", k):  # the scene's one cost probe launch (the counting variant): not a timed dispatch
+            continue
         key = "trace" if "rtmi_trace_kernel" in k else "resolve" if "rtmi_resolve" in k else None
         if key:
             per.setdefault(key, {})[m.group(2)] = float(m.group(3))
