@@ -135,10 +135,6 @@ typedef struct rtmi_tuning {
                                  * 2 = costliest first always */
     uint32_t bands;             /* a call whose sample records pass the cap (sample_buf_mb) is rendered in bands of rows, one after
                                  * the other: 0 / 1 = as many bands as the cap asks for (one if the call fits), n > 1 = at least n */
-    uint32_t sibling_lists;     /* HBM-resident trees: a ray segment that starts on a sphere of the tree tests the siblings along the
-                                 * way down to that sphere's leaf at set-up (stored per leaf) and starts its walk in that leaf,
-                                 * instead of descending to it from the top: 0 = on for trees that stay in HBM, 1 = off,
-                                 * 2 = on (trees in LDS never use them); same image either way */
 } rtmi_tuning;
 
 typedef struct rtmi_scene_options {
@@ -254,7 +250,6 @@ typedef struct rtmi_launch_info {
     uint32_t bands;         /* bands of rows it was rendered in (0: no call yet) */
     uint32_t tile_order;    /* 1: its tiles were handed out costliest first, 0: row by row */
     uint32_t probe_us;      /* duration of the scene's cost probe launch in microseconds (0: none was made) */
-    uint32_t sibling_lists; /* 1: walks of segments that start on a tree sphere start in that sphere's leaf (rtmi_tuning::sibling_lists) */
 } rtmi_launch_info;
 int rtmi_scene_get_launch_info(const rtmi_scene* scene, rtmi_launch_info* out);
 /* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), rmax^2}. */

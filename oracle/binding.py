@@ -216,13 +216,6 @@ def render_pixels_mt(cam, objs, mats, mt_seed, xy, counters=False):
     return (rgb, rgba, ctr.as_dict()) if counters else (rgb, rgba)
 
 
-def set_sibling_start(on):
-    """orc_set_sibling_start: the instrumented walk starts in the origin sphere's own leaf (what the library does for trees in HBM)."""
-    lib().orc_set_sibling_start.argtypes = [C.c_int]
-    lib().orc_set_sibling_start.restype = None
-    lib().orc_set_sibling_start(int(bool(on)))
-
-
 def render_rect_counter(cam, objs, mats, seed, x0, y0, x1, y1, nthreads=1, counters=False, bvh=None):
     """bvh = dict(nodes, slots, pad_classes, pad_eps, pad_floor) switches to the instrumented BVH walk."""
     w, h = x1 - x0, y1 - y0

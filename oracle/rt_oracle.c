@@ -599,14 +599,8 @@ static inline float ray_pad(const scene_t* sc, const ray_t* r, const float inv[3
     return e;
 }
 
-/* the object the current segment starts on, ~0u for a camera ray: for the walk's counters, and for the walk that starts in the
- * origin sphere's own leaf (orc_set_sibling_start) -- never for the image, which does not depend on the visiting order */
+/* instrumentation of the walk (counters only, never the image): the object the current segment starts on, ~0u for a camera ray */
 static __thread uint32_t g_origin_obj = 0xffffffffu;
-/* 1: a segment that starts on a sphere of the tree tests the siblings along the way down to that sphere's leaf (one box test per
- * level) and starts its walk in that leaf, as the library does for trees that stay in HBM (rtmi_tuning::sibling_lists,
- * csrc/rtmi_device.hip begin_segment): the instrumented walk then counts the box tests that kernel makes */
-static int g_sibling_start = 0;
-void orc_set_sibling_start(int on) { g_sibling_start = on; }
 static int path_to_slot(const scene_t* sc, uint32_t ref, uint32_t slot, uint32_t* path, int depth) {
     if (ref & 0x80000000u) {
         const uint32_t first = ref & 0x00ffffffu, count = (ref >> 24) & 0x7fu;
@@ -676,8 +670,7 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
     /* (counters) class of the segment and, for one that starts on a sphere inside the tree, the nodes above that sphere's leaf */
     int cls = 0, path_len = -1;
     uint32_t path[64];
-    uint32_t origin_slot = 0xffffffffu;
-    if (ctr || g_sibling_start) {
+    if (ctr) {
         if (g_origin_obj != 0xffffffffu) {
             cls = 1;
             uint32_t slot = 0xffffffffu;
@@ -686,35 +679,9 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
             if (slot != 0xffffffffu && !no_walk) {
                 path_len = path_to_slot(sc, cur, slot, path, 0);
                 if (path_len >= 0) cls = 2;
-                origin_slot = slot;
             }
         }
-        if (ctr) ctr->seg_class[cls]++;
-    }
-    if (g_sibling_start && path_len >= 0) {
-        /* the siblings along the way, root-most first (the deepest ends on top of the stack), each pruned by the padded slab test of
-         * the node step; then the walk starts in the origin's own leaf */
-        for (int q = 0; q < path_len; ++q) {
-            const orc_bvh_node* nd = &sc->nodes[path[q]];
-            int on;
-            if (q + 1 < path_len) on = nd->child[0] == path[q + 1] ? 0 : 1;
-            else {
-                const uint32_t c0 = nd->child[0];
-                on = ((c0 & 0x80000000u) && origin_slot >= (c0 & 0x00ffffffu) && origin_slot < (c0 & 0x00ffffffu) + ((c0 >> 24) & 0x7fu)) ? 0 : 1;
-            }
-            const int k = 1 - on;
-            float nmax = tmin, fmin_ = best_t;
-            for (int i = 0; i < 3; ++i) {
-                const float tc = fmaf(nd->ctr[k][i], inv[i], oinv[i]);
-                const float th = fmaf(nd->half[k][i], ainv[i], pinv[i]);
-                nmax = fmaxf(nmax, tc - th);
-                fmin_ = fminf(fmin_, tc + th);
-            }
-            if (ctr) ctr->node_tests += 1;
-            if (nmax <= fmin_) stack[sp++] = nd->child[k];
-            if (q + 1 == path_len) cur = nd->child[on];
-        }
-        path_len = -1; /* (the descent counters below describe the walk from the top) */
+        ctr->seg_class[cls]++;
     }
     for (; !no_walk;) {
         if (cur & 0x80000000u) {

@@ -165,10 +165,6 @@ int orc_render_rect_counter(const orc_camera* cam, const orc_object* objs, uint3
 /* Instrumented BVH walk (build-side extension): same image as the linear scan, counts node/sphere tests.
  * slots[i] = object index stored at leaf slot i; bounds used for the per-ray pad are in pad_classes
  * (n_classes x 8 floats: lo[3], hi[3], inv2rmin, unused). */
-/* 1: the instrumented walk starts, for a segment that begins on a sphere of the tree, in that sphere's own leaf after testing the
- * siblings along the way down to it -- what the library does for trees that stay in HBM; 0 (default): every walk from the top */
-void orc_set_sibling_start(int on);
-
 int orc_render_rect_counter_bvh(const orc_camera* cam, const orc_object* objs, uint32_t n_objs,
                                 const orc_material* mats, uint32_t n_mats, const orc_bvh_node* nodes, uint32_t n_nodes,
                                 const uint32_t* slots, uint32_t n_slots, const float* pad_classes, uint32_t n_classes,

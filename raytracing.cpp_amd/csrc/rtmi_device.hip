@@ -462,7 +462,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
         if (STATS) st_sphere += cnt;
     };
     auto begin_segment = [&](V3 o, V3 d) {
-        const uint32_t origin_leaf = t.cur; // (BIG walks: the leaf of the sphere this segment starts on, kNoLeaf for none)
         t.o = o;
         t.d = d;
         t.a = vdot(d, d);
@@ -527,69 +526,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                 pad = fmaxf(pad, ec);
             }
             t.pinv = mk(pad * __builtin_fabsf(t.inv.x), pad * __builtin_fabsf(t.inv.y), pad * __builtin_fabsf(t.inv.z));
-            // A segment that starts ON a sphere of the tree starts inside the box of every ancestor of that sphere's leaf: the walk
-            // from the top would descend to that leaf whatever the tree, one dependent node read per level, testing at each level
-            // the box it is in (always hit) and its sibling (config 4, the oracle's instrumented walk, tools/descent_score.py: 79 %
-            // of the segments start on a tree sphere, 15.05 of their 15.76 node trips are that descent, and the sibling is hit on
-            // 3.2 % of the levels).  Instead: the siblings along that way are stored per leaf (RtmiLaunch::sib), the segment tests
-            // them here -- one box per level, independent reads -- pushes the ones it hits, root-most first, and starts its walk in
-            // its own leaf.  Every leaf of the tree is in the own leaf or in exactly one of those siblings, a sibling is pruned by the
-            // same padded slab test the node step uses, and the closest hit does not depend on the visiting order: exact.
-            if (BIG && P.sib != nullptr && origin_leaf < kNoLeaf && P.root_ref != kNoWalk) {
-                // the leaf's record: {levels | own leaf reference's count << 16 ..., own leaf reference, 18 x u16 node indices of the
-                // way, root-most first}: three 16-byte loads, one round trip
-                const uint32_t* L = reinterpret_cast<const uint32_t*>(P.sib + (size_t)origin_leaf * P.sib_stride);
-                const uint32_t n_levels = L[0];
-                const uint32_t own = L[1];
-                // (the node indices are read where they are needed -- the 48-byte record is one or two cache lines, hit after the
-                // first touch -- rather than held in twelve registers across the loop)
-                const uint16_t* way = reinterpret_cast<const uint16_t*>(L + 2);
-                auto way_at = [&](uint32_t d) -> uint32_t { return (uint32_t)way[d]; };
-                const float ax = __builtin_fabsf(t.inv.x), ay = __builtin_fabsf(t.inv.y), az = __builtin_fabsf(t.inv.z);
-                typedef __attribute__((address_space(3))) uint32_t lds_u32;
-                auto load_node = [&](uint32_t node, uint4& n0, uint4& n1, uint4& n2) {
-                    if (node < P.lds_top_nodes) { // the staged top of the tree
-                        const lds_u32* np = (const lds_u32*)(uintptr_t)(lds0 + 48u * node);
-                        n0 = make_uint4(np[0], np[1], np[2], np[3]);
-                        n1 = make_uint4(np[4], np[5], np[6], np[7]);
-                        n2 = make_uint4(np[8], np[9], np[10], np[11]);
-                    } else {
-                        const uint4* np = lds_nodes + 3u * node;
-                        n0 = np[0]; n1 = np[1]; n2 = np[2];
-                    }
-                };
-                auto test_sibling = [&](const uint4 n0, const uint4 n1, const uint4 n2, uint32_t next) {
-                    // which child leads on (the next node of the way, or the own leaf at its end); the other one is tested
-                    const bool on0 = n2.y == next;
-                    const float cx = __uint_as_float(on0 ? n0.w : n0.x), cy = __uint_as_float(on0 ? n1.x : n0.y), cz = __uint_as_float(on0 ? n1.y : n0.z);
-                    const float hx = on0 ? half_hi(n1.w) : half_lo(n1.z), hy = on0 ? half_lo(n2.x) : half_hi(n1.z), hz = on0 ? half_hi(n2.x) : half_lo(n1.w);
-                    const uint32_t ref = on0 ? n2.z : n2.y;
-                    const float tcx = __builtin_fmaf(cx, t.inv.x, t.oinv.x), thx = __builtin_fmaf(hx, ax, t.pinv.x);
-                    const float tcy = __builtin_fmaf(cy, t.inv.y, t.oinv.y), thy = __builtin_fmaf(hy, ay, t.pinv.y);
-                    const float tcz = __builtin_fmaf(cz, t.inv.z, t.oinv.z), thz = __builtin_fmaf(hz, az, t.pinv.z);
-                    const float tn = fmaxf(fmaxf(tcx - thx, tcy - thy), fmaxf(tcz - thz, 0.0001f));
-                    float zf = tcz + thz;
-                    asm("v_min_f32 %0, %1, %2" : "=v"(zf) : "v"(zf), "v"(t.tbest));
-                    const float tf = fminf(fminf(tcx + thx, tcy + thy), zf);
-                    if (STATS) st_node += 1;
-                    if (tn <= tf) {
-                        *stack_at(t.sp) = (StackS)ref;
-                        t.sp += sp_stride;
-                    }
-                };
-                t.cur = own; // the walk's first step: the own leaf
-                // two levels per trip: six node reads in flight (the levels do not depend on each other: the way is known)
-                for (uint32_t lv = 0; lv < n_levels; lv += 2u) {
-                    const bool two = lv + 1u < n_levels;
-                    const uint32_t na = way_at(lv), nb = two ? way_at(lv + 1u) : na;
-                    const uint32_t nxt_b = lv + 2u < n_levels ? way_at(lv + 2u) : own;
-                    uint4 a0, a1, a2, b0, b1, b2;
-                    load_node(na, a0, a1, a2);
-                    load_node(nb, b0, b1, b2);
-                    test_sibling(a0, a1, a2, two ? nb : own);
-                    if (two) test_sibling(b0, b1, b2, nxt_b);
-                }
-            }
             PF_MARK(19);
         } else {
             t.cur = 0; // next sphere of the linear scan
@@ -712,7 +648,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             } else {
                 t.o = origin;
                 t.d = vsub(pixel_sample, origin);
-                if (BIG && ACCEL == RTMI_ACCEL_BVH) t.cur = kNoLeaf; // a camera ray starts on no sphere
                 phase = PH_BEGIN;
             }
         }
@@ -878,7 +813,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
         ISA_MARK("request");
         __builtin_amdgcn_s_setprio(0);
         uint32_t rq = RQ_NONE; // Lambertian / Metallic hit: a unit vector; Dielectric hit: one draw
-        if (phase == PH_SHADE && t.best < kBlackSample) rq = (lds_aux[t.best].w & 3u) != 2u ? RQ_UNIT : RQ_WORD;
+        if (phase == PH_SHADE && t.best < kBlackSample) rq = lds_aux[t.best].w != 2u ? RQ_UNIT : RQ_WORD;
         PF_MARK(4);
         ISA_MARK("draws");
         rng.sample = s; // (defined where it is used: not a register across the walk)
@@ -891,7 +826,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
         PB(15, phase == PH_SHADE && t.best == ~0u && (natt != 0u || run_n != 0u));
 #if defined(RTMI_PROF) && RTMI_PROF == 2
         { // (census votes are taken outside the divergent code they describe: inside it the compiler may move them)
-            const uint32_t kind_c = (phase == PH_SHADE && t.best < kBlackSample) ? (lds_aux[t.best].w & 3u) : 3u;
+            const uint32_t kind_c = (phase == PH_SHADE && t.best < kBlackSample) ? lds_aux[t.best].w : 3u;
             PB(10, kind_c == 0u);
             PB(11, kind_c == 1u);
             PB(12, kind_c == 2u);
@@ -925,7 +860,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                 const uint4 m0 = lds_mats[mh]; // {albedo, fuzz} or {refraction index, ...}
                 ISA_MARK("shade-material");
                 PF_MARK(9);
-                const uint32_t kind = araw.w & 3u; // (the upper bits: the leaf of the slot, for the next segment's set-up)
+                const uint32_t kind = araw.w;
                 V3 sd = mk(0.0f, 0.0f, 0.0f);
                 bool scattered = true;
                 if (kind != 2u) {
@@ -977,7 +912,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                     } else {
                         t.o = p;
                         t.d = sd;
-                        if (BIG && ACCEL == RTMI_ACCEL_BVH) t.cur = araw.w >> 2; // where the next segment starts (begin_segment reads it)
                         phase = PH_BEGIN; // set up before the next traversal, together with the new primary rays
                     }
                 }
@@ -1323,8 +1257,6 @@ struct rtmi_scene {
     uint4* d_aux = nullptr;
     uint4* d_mats = nullptr;
     uint4* d_nodes = nullptr;
-    uint4* d_sib = nullptr;      // HBM-resident trees: per-leaf sibling lists (RtmiLaunch::sib)
-    uint32_t sib_stride = 0;     // uint4 per leaf
     unsigned long long* d_stats = nullptr;
     unsigned long long* d_tail = nullptr; // -DRTMI_TAILPROBE builds only
     float* d_rgb = nullptr;     // staging for rtmi_render_rows / rtmi_render_rect (host-pointer entries)
@@ -1407,7 +1339,6 @@ void free_scene(rtmi_scene* s) {
     hipFree(s->d_aux);
     hipFree(s->d_mats);
     hipFree(s->d_nodes);
-    hipFree(s->d_sib);
     hipFree(s->d_stats);
     hipFree(s->d_tail);
     hipFree(s->d_rgb);
@@ -1431,8 +1362,6 @@ void fill_scene_params(const rtmi_scene* s, RtmiLaunch& P) {
     P.aux = s->d_aux;
     P.mats = s->d_mats;
     P.nodes = s->d_nodes;
-    P.sib = s->d_sib;
-    P.sib_stride = s->sib_stride;
     P.n_slots = s->n_objects;
     P.n_mats = s->n_mats;
     P.n_nodes = (uint32_t)s->bvh.nodes.size();
@@ -1943,7 +1872,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         // Radius * Radius of object.defs.cc:46 is the same float for every ray: computed once here
         const float r2 = o.radius * o.radius;
         h_spheres[i] = make_uint4(fbits(o.center[0]), fbits(o.center[1]), fbits(o.center[2]), fbits(r2));
-        h_aux[i] = make_uint4(slot_object[i], o.material, fbits(o.radius), materials[o.material].kind | (kNoLeaf << 2)); // (.w: kind | leaf of the slot << 2)
+        h_aux[i] = make_uint4(slot_object[i], o.material, fbits(o.radius), materials[o.material].kind);
     }
     for (uint32_t i = 0; i < n_materials; ++i) {
         const rtmi_material& m = materials[i];
@@ -2036,6 +1965,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         return e;
     };
     HIP_TRY_S(upload(&s->d_spheres, h_spheres.data(), h_spheres.size() * sizeof(uint4)));
+    HIP_TRY_S(upload(&s->d_aux, h_aux.data(), h_aux.size() * sizeof(uint4)));
     HIP_TRY_S(upload(&s->d_mats, h_mats.data(), h_mats.size() * sizeof(uint4)));
     {
         // device copy of the nodes: LDS-resident scenes get their references in the 16-bit stack-entry form
@@ -2055,7 +1985,6 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         }
         // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start
         // every walk below them
-        uint32_t walk_start = s->bvh.root_ref; // (host form) where every walk starts once the spine's leaves are peeled off
         if (s->accel == RTMI_ACCEL_BVH && !dn.empty()) {
             uint32_t cur = s->bvh.root_ref;
             while (!(cur & kLeafBit) && s->n_pre_leaves < 4u) {
@@ -2073,7 +2002,6 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
                 cur = l0 ? nd.child[1] : nd.child[0];
             }
             if (s->n_pre_leaves) s->root_ref_dev = (cur == kNoWalk) ? kNoWalk : (s->big ? cur : pack16(cur));
-            walk_start = cur;
         }
         if (!dn.empty()) {
             // 48-byte records: centres fp32, half extents fp16 rounded up (an extent beyond fp16 becomes +inf: always hit),
@@ -2114,67 +2042,10 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
                 r[10] = dn[i].child[1];
             }
             HIP_TRY_S(upload(&s->d_nodes, rec.data(), rec.size() * sizeof(uint32_t)));
-            // Per-leaf ways for trees that stay in HBM (RtmiLaunch::sib; begin_segment): for every leaf below the walk's start, the
-            // nodes on the way down to it, root-most first, as 16-bit indices (trees of up to 65 535 nodes, 20 levels): 48 bytes a
-            // leaf, 1.2 MB for the 24 965 leaves of config 4.  The sibling boxes themselves are read from the node records -- the
-            // staged top of the tree from LDS.  (A first version stored the sibling boxes per leaf, 32 bytes a level, 14.4 MB: every
-            // level a read through L2, the top of the tree included -- 84.4 ms against 73.8 without, config 4 at 64 spp.)
-            const bool want_sib = tune.sibling_lists == 2u || (tune.sibling_lists == 0u && s->big);
-            if (want_sib && s->big && s->accel == RTMI_ACCEL_BVH && walk_start != kNoWalk) {
-                struct Frame { uint32_t ref; uint32_t depth; };
-                // pass 1: leaves and the deepest of them
-                uint32_t n_leaves = 0, max_levels = 0;
-                std::vector<Frame> st{{walk_start, 0u}};
-                while (!st.empty()) {
-                    const Frame f = st.back();
-                    st.pop_back();
-                    if (f.ref & kLeafBit) {
-                        ++n_leaves;
-                        max_levels = std::max(max_levels, f.depth);
-                    } else {
-                        st.push_back({s->bvh.nodes[f.ref].child[1], f.depth + 1u});
-                        st.push_back({s->bvh.nodes[f.ref].child[0], f.depth + 1u});
-                    }
-                }
-                // per leaf three uint4: {levels, own leaf reference, 20 x u16 node indices of the way down to it}
-                const uint32_t stride4 = 3u; // uint4 per leaf
-                const bool fits = max_levels <= 20u && s->bvh.nodes.size() <= 0xffffu;
-                std::vector<uint32_t> lists(fits ? (size_t)n_leaves * stride4 * 4u : 0u, 0u);
-                // pass 2: depth-first with the way down kept explicitly
-                std::vector<uint32_t> way;
-                struct Visit { uint32_t ref; uint32_t depth; uint32_t parent; };
-                std::vector<Visit> vs;
-                if (fits) vs.push_back({walk_start, 0u, 0u});
-                uint32_t leaf_id = 0;
-                while (!vs.empty()) {
-                    const Visit v = vs.back();
-                    vs.pop_back();
-                    way.resize(v.depth);
-                    if (v.depth) way[v.depth - 1u] = v.parent;
-                    if (v.ref & kLeafBit) {
-                        uint32_t* L = &lists[(size_t)leaf_id * stride4 * 4u];
-                        L[0] = v.depth; // levels
-                        L[1] = v.ref;   // the leaf's own reference
-                        for (uint32_t d = 0; d < v.depth; ++d) L[2u + (d >> 1)] |= (way[d] & 0xffffu) << (16u * (d & 1u));
-                        const uint32_t first = v.ref & 0x00ffffffu, count = (v.ref >> 24) & 0x7fu;
-                        for (uint32_t q = first; q < first + count && q < n_objects; ++q)
-                            h_aux[q].w = (h_aux[q].w & 3u) | (leaf_id << 2);
-                        ++leaf_id;
-                    } else {
-                        vs.push_back({s->bvh.nodes[v.ref].child[1], v.depth + 1u, v.ref});
-                        vs.push_back({s->bvh.nodes[v.ref].child[0], v.depth + 1u, v.ref});
-                    }
-                }
-                if (fits && leaf_id != 0u && leaf_id < kNoLeaf) {
-                    HIP_TRY_S(upload(&s->d_sib, lists.data(), lists.size() * sizeof(uint32_t)));
-                    s->sib_stride = stride4;
-                }
-            }
         } else {
             HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
         }
     }
-    HIP_TRY_S(upload(&s->d_aux, h_aux.data(), h_aux.size() * sizeof(uint4))); // (after the tree: .w carries the leaf of every slot)
 
     // persistent grid: exactly as many workgroups as the device keeps resident
     KernelFn fn = pick_kernel(s->accel, s->collect_stats, s->big, 0);
@@ -2420,7 +2291,6 @@ extern "C" int rtmi_scene_get_launch_info(const rtmi_scene* s, rtmi_launch_info*
     v.bands = s->last_bands;
     v.tile_order = s->last_tile_order;
     v.probe_us = s->cost_state == 1 ? (uint32_t)(s->probe_ms * 1000.0f + 0.5f) : 0u;
-    v.sibling_lists = s->d_sib != nullptr ? 1u : 0u;
     std::memcpy(out, &v, std::min<size_t>(out->struct_size, sizeof(v)));
     return RTMI_OK;
 }

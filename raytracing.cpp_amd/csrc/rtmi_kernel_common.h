@@ -33,7 +33,7 @@ struct RtmiLaunch {
     rtmi_camera cam;
     // scene, global memory (staged into LDS by every workgroup)
     const uint4* spheres;  // [n_slots] {cx, cy, cz, r*r} as bits
-    const uint4* aux;      // [n_slots] {object index, material handle, radius bits, MaterialKind of that handle | leaf of the slot << 2 (kNoLeaf: none)}
+    const uint4* aux;      // [n_slots] {object index, material handle, radius bits, MaterialKind of that handle}
     const uint4* mats;     // [n_mats]  {p0, p1, p2, p3} (albedo + fuzz, or refraction index in p0); the kind rides in aux.w
     const uint4* nodes;    // [n_nodes] 3 x uint4 per node (48-byte records, see unpack_node48)
     uint32_t n_slots, n_mats, n_nodes, root_ref;
@@ -60,11 +60,6 @@ struct RtmiLaunch {
     // probe launches (STATS variants only): segments per 8x8 tile of the WHOLE image, tile = (gy / 8) * gtiles_x + px / 8
     uint32_t* tile_cost;
     uint32_t gtiles_x;
-    // HBM-resident trees: per leaf, the way from the walk's start down to it -- sib_stride (3) uint4: {levels, the leaf's own
-    // reference, 20 x u16 node indices, root-most first}.  A segment that starts on a sphere of the tree tests the siblings along
-    // that way at set-up and starts its walk in its own leaf (begin_segment).  NULL: every walk starts at the top.
-    const uint4* sib;
-    uint32_t sib_stride;
     unsigned long long* tail_probe; // -DRTMI_TAILPROBE builds only: per wave {start, first refill past the end, exit} in 100 MHz ticks
     // sample-chunk split: a work item is `chunk` consecutive samples of one pixel; their colours go to sample_buf
     // ([pixel][sample] float4) and rtmi_resolve_kernel adds them up in sample order.  n_chunks == 1: a lane owns
@@ -454,7 +449,6 @@ DEV V3 coop_draws(uint32_t code, Rng& rng, uint64_t seed, lds_u8* tbl PB_ARGS) {
 // ---------------------------------------------------------------------------------------------------------
 enum : uint32_t { PH_FETCH = 0, PH_GEN = 1, PH_TRAV = 2, PH_SHADE = 3, PH_DONE = 4, PH_BEGIN = 5 };
 constexpr uint32_t kNoWalk = 0xffffffffu; // RtmiLaunch::root_ref: every leaf is tested at segment set-up
-constexpr uint32_t kNoLeaf = 0x3fffffffu; // aux.w >> 2 of a sphere outside the walked tree (a peeled leaf: the ground); Trav::cur of a camera ray before set-up
 constexpr uint32_t kAttLds = 4; // closed attenuation runs kept in LDS per lane; more material changes spill to HBM
 
 struct Trav { // per-segment traversal state

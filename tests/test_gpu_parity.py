@@ -878,7 +878,7 @@ def test_differential_fuzz_slice(pkg, ob, gpu):
         for accel in (pkg.ACCEL_BVH, pkg.ACCEL_BRUTE):
             tunings = (None, dict(force_hbm_scene=1, chain_mode=1), dict(chunk_samples=-1), dict(tile_order=2, bands=3, chunk_samples=2))
             if accel == pkg.ACCEL_BVH:  # (two of the four walk-only variants per world)
-                tunings += ((dict(pad_mode=2), dict(pad_mode=1, force_hbm_scene=1, lds_top_nodes=10, bvh_passes=9, sibling_lists=1)) if case % 2 else
+                tunings += ((dict(pad_mode=2), dict(pad_mode=1, force_hbm_scene=1, lds_top_nodes=10, bvh_passes=9)) if case % 2 else
                             (dict(pad_mode=1, bvh_passes=1), dict(pad_mode=2, force_hbm_scene=1, lds_top_nodes=1)))
             for tun in tunings:
                 with pkg.Scene(cam, objs, mats, accel=accel, tuning=tun) as s:
@@ -920,9 +920,7 @@ def test_box_pad_rules_count_the_same_tests_as_the_oracle_walk(pkg, ob, gpu):
                         rgb, _ = s.render_rows(0, cam.img_height, 31)
                         st = s.stats()
                         bvh = s.bvh()
-                        lists = s.launch_info()["sibling_lists"]  # (trees in HBM: walks start in the origin sphere's leaf, next test)
                     ob.set_pad_mode(mode)
-                    ob.set_sibling_start(bool(lists))
                     want, _, c = ob.render_rect_counter(ocam, objs, mats, 31, 0, 0, ocam.img_width, ocam.img_height, nthreads=8,
                                                         counters=True, bvh=bvh)
                     _assert_frames_equal(rgb, want)
@@ -933,55 +931,6 @@ def test_box_pad_rules_count_the_same_tests_as_the_oracle_walk(pkg, ob, gpu):
             assert counts[0, 0] == counts[auto_is, 0] and counts[2, 0] <= counts[1, 0]
     finally:
         ob.set_pad_mode(0)
-        ob.set_sibling_start(False)
-
-
-def test_walks_that_start_in_the_origin_leaf(pkg, ob, rtow, gpu):
-    """Trees that stay in HBM (round 5): a ray segment that starts ON a sphere of the tree is inside the box of every ancestor of
-    that sphere's leaf, so the walk from the top descends to that leaf whatever the tree -- on the 100k-sphere grid 15 of the 15.8
-    node trips of such a segment (tools/descent_score.py).  The library stores, per leaf, the siblings along that way; the segment
-    tests them at set-up (one box per level), pushes the ones it hits and starts in its own leaf.  Same image as the walk from the
-    top and as the oracle's linear scan, on a wide grid and on S-RTOW forced into HBM, both pad rules; the box tests the kernel
-    counts are the ones the oracle's walk counts when it starts the same way, and fewer than from the top; the report says which
-    way a scene walks; trees in LDS never use the lists."""
-    worlds = []
-    objs, mats, kw = big_grid(100, seed=9)
-    worlds.append((objs, mats, dict(kw, image_width=112, samples_per_pixel=6, max_depth=30)))
-    worlds.append((*rtow, dict(image_width=112, samples_per_pixel=6, max_depth=50)))
-    try:
-        for objs, mats, kw in worlds:
-            cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
-            want, want8 = ob.render_rect_counter(ocam, objs, mats, 66, 0, 0, ocam.img_width, ocam.img_height, nthreads=8)  # linear scan
-            tests = {}
-            for lists in (0, 1, 2):  # default (on for trees in HBM), off, on
-                for pad in (1, 2):
-                    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, collect_stats=True,
-                                   tuning=dict(force_hbm_scene=1, sibling_lists=lists, pad_mode=pad)) as s:
-                        assert s.launch_info()["sibling_lists"] == (0 if lists == 1 else 1) and s.launch_info()["scene_in_lds"] == 0
-                        rgb, rgba = s.render_rows(0, cam.img_height, 66)
-                        st = s.stats()
-                        bvh = s.bvh()
-                    _assert_frames_equal(rgb, want)
-                    assert np.array_equal(rgba, want8)
-                    ob.set_pad_mode(pad)
-                    ob.set_sibling_start(lists != 1)
-                    _, _, c = ob.render_rect_counter(ocam, objs, mats, 66, 0, 0, ocam.img_width, ocam.img_height, nthreads=8, counters=True, bvh=bvh)
-                    assert st["segments"] == c["segments"]
-                    assert abs(st["node_tests"] - c["node_tests"]) <= 1e-3 * c["node_tests"], (lists, pad, st, c)
-                    assert abs(st["sphere_tests"] - c["sphere_tests"]) <= 1e-3 * c["sphere_tests"], (lists, pad)
-                    tests[lists, pad] = st["node_tests"]
-                    # the shipped (non-counting) kernel variant, sample records and whole-pixel items
-                    for tun in (dict(), dict(chunk_samples=-1)):
-                        with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=dict(tun, force_hbm_scene=1, sibling_lists=lists, pad_mode=pad)) as s:
-                            rgb, _ = s.render_rows(0, cam.img_height, 66)
-                        _assert_frames_equal(rgb, want)
-            assert tests[0, 1] == tests[2, 1] < tests[1, 1] and tests[0, 2] < tests[1, 2]
-            with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, tuning=dict(sibling_lists=2)) as s:  # in LDS where it fits: no lists
-                if s.launch_info()["scene_in_lds"]:
-                    assert s.launch_info()["sibling_lists"] == 0
-    finally:
-        ob.set_pad_mode(0)
-        ob.set_sibling_start(False)
 
 
 def test_kernel_statistics_match_oracle_counters(pkg, ob, rtow, gpu):

@@ -22,7 +22,7 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
         tunings = (None, dict(force_hbm_scene=1), dict(chain_mode=1), dict(chunk_samples=-1), dict(tile_order=2, bands=3, chunk_samples=2))
         if accel == pkg.ACCEL_BVH:
             tunings += (dict(pad_mode=2), dict(pad_mode=1, bvh_passes=1), dict(pad_mode=2, force_hbm_scene=1, lds_top_nodes=1),
-                        dict(pad_mode=1, force_hbm_scene=1, lds_top_nodes=10, bvh_passes=9), dict(force_hbm_scene=1, sibling_lists=1))
+                        dict(pad_mode=1, force_hbm_scene=1, lds_top_nodes=10, bvh_passes=9))
         for tun in tunings:
             with pkg.Scene(cam, objs, mats, accel=accel, tuning=tun) as s:
                 rgb, rgba = s.render_rows(0, cam.img_height, case)
