@@ -81,6 +81,9 @@ def test_scene_create_argument_errors(pkg):
     assert e.value.code == pkg.RTMI_ERR_BAD_ARG
     assert pkg.lib().rtmi_scene_create(None, None, 0, None, 0, None, None) == pkg.RTMI_ERR_BAD_ARG
     assert pkg.lib().rtmi_render_rows(None, 0, 1, 0, None, None) == pkg.RTMI_ERR_BAD_ARG
+    assert pkg.lib().rtmi_render_rect(None, 0, 0, 8, 8, 0, None, None) == pkg.RTMI_ERR_BAD_ARG  # the tile-granular entries of 0.5
+    assert pkg.lib().rtmi_render_rect_device(None, 0, 0, 8, 8, 0, None, None, None) == pkg.RTMI_ERR_BAD_ARG
+    assert b"null scene" in pkg.lib().rtmi_last_error()
     info = pkg.LaunchInfo()
     info.struct_size = C.sizeof(pkg.LaunchInfo)
     assert pkg.lib().rtmi_scene_get_launch_info(None, C.byref(info)) == pkg.RTMI_ERR_BAD_ARG
