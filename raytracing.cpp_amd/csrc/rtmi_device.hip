@@ -1049,7 +1049,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
 
 // Ordered resolve of the sample-chunk split: pixel_color += sample, s = 0 .. spp-1, exactly the sequential fp32 sum of
 // raytrace_pixel (core.cc:260-263), then * pixels_sample_scale and RGBAColor (core.cc:264, color.hpp:30-36).
-// One lane per pixel, 64 bytes per lane and trip: HBM-bound (5.2 TB/s at 1080p x 512 spp).
+// One lane per pixel, 128 bytes per lane and trip: HBM-bound (5.7 TB/s at 1080p x 512 spp).
 struct ResolveArgs;
 DEV void resolve_store(const ResolveArgs& A, uint32_t p, V3 sum);
 struct ResolveArgs {
@@ -1080,13 +1080,28 @@ DEV void resolve_store(const ResolveArgs& A, uint32_t p, V3 sum) {
     }
 }
 
-__global__ void __launch_bounds__(256) rtmi_resolve_kernel(const ResolveArgs A) {
+// (round 5, rocprofv3 kernel stats on the 1080p x 512 spp frame: 4 records a trip in blocks of 256 lanes 3.285 ms, 8 a trip -- a whole 128-byte
+// line per lane -- 3.090, 8 a trip in blocks of 64 lanes 2.998 ms = 5.7 TB/s; 4 a trip in blocks of 64: 3.331)
+#define RTMI_RESOLVE_BLOCK 64
+__global__ void __launch_bounds__(RTMI_RESOLVE_BLOCK) rtmi_resolve_kernel(const ResolveArgs A) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.n_pixels) return;
     const uint32_t spp = A.spp;
     const float4* src = A.sample_buf + (size_t)p * spp;
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     uint32_t k = 0;
+    for (; k + 8u <= spp; k += 8u) { // a whole 128-byte line per lane and trip
+        const float4 c0 = src[k], c1 = src[k + 1u], c2 = src[k + 2u], c3 = src[k + 3u];
+        const float4 c4 = src[k + 4u], c5 = src[k + 5u], c6 = src[k + 6u], c7 = src[k + 7u];
+        sum = vadd(sum, mk(c0.x, c0.y, c0.z));
+        sum = vadd(sum, mk(c1.x, c1.y, c1.z));
+        sum = vadd(sum, mk(c2.x, c2.y, c2.z));
+        sum = vadd(sum, mk(c3.x, c3.y, c3.z));
+        sum = vadd(sum, mk(c4.x, c4.y, c4.z));
+        sum = vadd(sum, mk(c5.x, c5.y, c5.z));
+        sum = vadd(sum, mk(c6.x, c6.y, c6.z));
+        sum = vadd(sum, mk(c7.x, c7.y, c7.z));
+    }
     for (; k + 4u <= spp; k += 4u) { // a whole 64-byte line per lane and trip
         const float4 c0 = src[k], c1 = src[k + 1u], c2 = src[k + 2u], c3 = src[k + 3u];
         sum = vadd(sum, mk(c0.x, c0.y, c0.z));
@@ -1668,7 +1683,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         A.scale = s->cam.pixels_sample_scale;
         A.out_rgb = d_rgb;
         A.out_rgba = d_rgba;
-        const dim3 rgrid((A.n_pixels + 255u) / 256u);
+        const dim3 rgrid((A.n_pixels + RTMI_RESOLVE_BLOCK - 1u) / RTMI_RESOLVE_BLOCK);
         if (mode == 4) {
             A.chain_buf = P.chain_buf;
             A.mats = s->d_mats;
@@ -1684,7 +1699,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(rtmi_resolve_chain_kernel, dim3(std::max(1u, blocks)), dim3(256), lds, stream, A);
         } else {
-            hipLaunchKernelGGL(rtmi_resolve_kernel, rgrid, dim3(256), 0, stream, A);
+            hipLaunchKernelGGL(rtmi_resolve_kernel, rgrid, dim3(RTMI_RESOLVE_BLOCK), 0, stream, A);
         }
         HIP_TRY(hipGetLastError());
     }
