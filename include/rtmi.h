@@ -135,6 +135,8 @@ typedef struct rtmi_tuning {
                                  * 2 = costliest first always */
     uint32_t bands;             /* a call whose sample records pass the cap (sample_buf_mb) is rendered in bands of rows, one after
                                  * the other: 0 / 1 = as many bands as the cap asks for (one if the call fits), n > 1 = at least n */
+    uint32_t gen_ahead;         /* packed-chain scenes: primary rays generated ahead into per-lane LDS slots (whenever some lane must
+                                 * generate one, the others generate their next sample's): 0 = where the slots fit, 1 = off */
 } rtmi_tuning;
 
 typedef struct rtmi_scene_options {
@@ -250,6 +252,7 @@ typedef struct rtmi_launch_info {
     uint32_t bands;         /* bands of rows it was rendered in (0: no call yet) */
     uint32_t tile_order;    /* 1: its tiles were handed out costliest first, 0: row by row */
     uint32_t probe_us;      /* duration of the scene's cost probe launch in microseconds (0: none was made) */
+    uint32_t gen_ahead;     /* 1: primary rays are generated ahead into LDS slots (rtmi_tuning::gen_ahead) */
 } rtmi_launch_info;
 int rtmi_scene_get_launch_info(const rtmi_scene* scene, rtmi_launch_info* out);
 /* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), rmax^2}. */

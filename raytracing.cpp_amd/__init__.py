@@ -81,7 +81,7 @@ class Tuning(C.Structure):  # rtmi_tuning: scheduling knobs, 0 = default; none o
                 ("chain_mode", C.c_int32), ("bvh_passes", C.c_uint32), ("sample_buf_mb", C.c_uint32),
                 ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("kernel", C.c_uint32),
                 ("reserved3", C.c_uint32 * 3), ("lds_top_nodes", C.c_uint32), ("tile_order", C.c_uint32),
-                ("bands", C.c_uint32)]
+                ("bands", C.c_uint32), ("gen_ahead", C.c_uint32)]
 
 
 class SceneOptions(C.Structure):
@@ -93,7 +93,7 @@ class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("struct_size", "kernel", "block_lanes", "grid_blocks", "blocks_per_cu",
                                           "lds_bytes", "scene_in_lds", "stack_depth", "whole_pixel_fallbacks",
                                           "packed_chains", "packed_chain_fallbacks", "lds_top_nodes", "pad_mode",
-                                          "bands", "tile_order", "probe_us")]
+                                          "bands", "tile_order", "probe_us", "gen_ahead")]
 
 
 class FrameTiming(C.Structure):

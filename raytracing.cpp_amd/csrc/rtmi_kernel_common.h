@@ -47,6 +47,7 @@ struct RtmiLaunch {
     // LDS carve-up (byte offsets)
     uint32_t lds_spheres, lds_aux, lds_mats, lds_nodes, lds_stack, stack_depth, lds_att, lds_pool;
     uint32_t lds_top_nodes;   // HBM-resident trees: this many breadth-first nodes (48-byte records) start the LDS segment
+    uint32_t lds_ahead;       // packed-chain launches: byte offset of the per-lane slots of primary rays generated ahead (0: none), see the GEN phase
     // image rows handled by this launch
     uint32_t y_first, block_rows, block_stride, n_local_rows;
     uint32_t x_first, x_end, local_w; // columns [x_first, x_end) of every row (rtmi_render_rect; whole rows: 0, W, W); local_w = x_end - x_first

@@ -206,10 +206,15 @@ def test_packed_and_run_length_attenuation_chains(pkg, ob, rtow, gpu):
     g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
     ccam = pkg.camera_setup(pkg.camera_params(**json.loads(str(g["camera"]))))
     for tun, packed in ((None, True), (dict(chain_mode=1), False), (dict(sample_buf_mb=1), True), (dict(chunk_samples=-1), True),
-                        (dict(block_lanes=512, chunk_samples=5), True)):
+                        (dict(block_lanes=512, chunk_samples=5), True), (dict(gen_ahead=1), True), (dict(gen_ahead=1, chunk_samples=3), True),
+                        (dict(chunk_samples=2), True)):
         for accel, _ in _both(pkg):
             with pkg.Scene(ccam, g["objects"], g["materials"], accel=accel, tuning=tun) as s:
                 assert (s.launch_info()["packed_chains"] > 0) == packed
+                # packed-chain launches generate primary rays ahead into LDS slots where these fit (round 5): on by default for the
+                # scan of this box, off on request, never for run-length encoded chains
+                if accel == pkg.ACCEL_BRUTE:
+                    assert s.launch_info()["gen_ahead"] == (1 if packed and not (tun or {}).get("gen_ahead") else 0), (tun, s.launch_info())
                 rgb, rgba = s.render_rows(0, ccam.img_height, int(g["seed"]))
                 part, _ = s.render_rows(7, 19, int(g["seed"]))
                 assert s.launch_info()["packed_chain_fallbacks"] == 0  # what was launched is what the scene is eligible for

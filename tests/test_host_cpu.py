@@ -87,7 +87,7 @@ def test_scene_create_argument_errors(pkg):
     info = pkg.LaunchInfo()
     info.struct_size = C.sizeof(pkg.LaunchInfo)
     assert pkg.lib().rtmi_scene_get_launch_info(None, C.byref(info)) == pkg.RTMI_ERR_BAD_ARG
-    assert C.sizeof(pkg.LaunchInfo) == 64  # 40 in version 0.3, 52 in 0.4: the struct grows at its end, struct_size tells the library what fits
+    assert C.sizeof(pkg.LaunchInfo) == 68  # 40 in version 0.3, 52 in 0.4: the struct grows at its end, struct_size tells the library what fits
     pkg.lib().rtmi_scene_destroy(None)  # no-op
 
 
@@ -133,7 +133,7 @@ def test_frame_create_argument_errors(pkg):
 
 
 def test_tuning_struct_layout_and_unknown_knobs(pkg):
-    assert C.sizeof(pkg.Tuning) == 72 and C.sizeof(pkg.SceneOptions) == 40  # (64 in 0.4: the struct grows at its end)
+    assert C.sizeof(pkg.Tuning) == 76 and C.sizeof(pkg.SceneOptions) == 40  # (64 in 0.4: the struct grows at its end)
     with pytest.raises(KeyError):
         pkg.make_tuning(no_such_knob=1)
     header = open(os.path.join(ROOT, "include", "rtmi.h")).read()
@@ -250,7 +250,7 @@ def test_header_is_plain_c_and_every_prototype_is_exported(pkg, tmp_path):
     src = tmp_path / "hc.c"
     src.write_text('#include "rtmi.h"\n'
                    'int main(void) { return (sizeof(rtmi_object) == 24 && sizeof(rtmi_material) == 20 && sizeof(rtmi_camera) == 100\n'
-                   '                         && sizeof(rtmi_bvh_node) == 64 && sizeof(rtmi_launch_info) == 64 && sizeof(rtmi_tuning) == 72) ? 0 : 1; }\n')
+                   '                         && sizeof(rtmi_bvh_node) == 64 && sizeof(rtmi_launch_info) == 68 && sizeof(rtmi_tuning) == 76) ? 0 : 1; }\n')
     exe = tmp_path / "hc"
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
