@@ -19,8 +19,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "librtmi.so")
 CSRC = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_host.cpp", "rtmi_device.hip", "rtmi_frame.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "rtmi_internal.h"), os.path.join(_HERE, "csrc", "rtmi_kernel_common.h"),
-           os.path.join(_ROOT, "include", "rtmi.h")]
+HEADERS = [os.path.join(_HERE, "csrc", f) for f in ("rtmi_internal.h", "rtmi_kernel_common.h", "rtmi_walk_asm.h",
+                                                     "rtmi_trace_kernel.h", "rtmi_resolve.h")] + [
+    os.path.join(_ROOT, "include", "rtmi.h")]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

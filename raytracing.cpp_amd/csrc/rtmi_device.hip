@@ -1,5 +1,9 @@
 // rtmi_device.hip -- the per-pixel path-tracing hot loop as hand-written HIP for gfx950 (CDNA4), and the
-// C-ABI entry points that need the HIP runtime.
+// C-ABI entry points that need the HIP runtime.  One translation unit along its seams:
+//   rtmi_walk_asm.h      the two hand-scheduled node loops of the BVH walk
+//   rtmi_trace_kernel.h  rtmi_trace_kernel<ACCEL, STATS, BIG, MODE>
+//   rtmi_resolve.h       the resolve passes (ordered per-pixel sum; packed chains)
+//   this file            scene handle, launch scheduling (bands, tile order, probe), entry points
 //
 // Replaces, from the reference (adihodos/raytracing.cpp):
 //   RayTracingCore::raytrace_pixel / get_ray / compute_color      src/ray.tracer.core.cc:218-265
@@ -48,1216 +52,8 @@
 
 #include "rtmi_kernel_common.h"
 
-constexpr uint32_t kBlackSample = 0xfffffffeu; // Trav::best of a sample that is finished without tracing (maxdepth == 0)
-
-#ifndef RTMI_WPE
-#define RTMI_WPE 6 // waves per SIMD the register allocation aims at (A/B: 7 = 72 VGPRs + 20 B of scratch, 4 % slower)
-#endif
-
-#ifndef RTMI_WPE_BIG
-#define RTMI_WPE_BIG 6 // HBM-resident scenes: 8 = 64 VGPRs, the compiler's walk, two 896-lane workgroups per CU (round 2);
-                       // 6 = the hand-written node loop (v66-v79 are its node registers), two 768-lane workgroups
-#endif
-
-#ifndef RTMI_WALK_PRIO
-#define RTMI_WALK_PRIO 1 // s_setprio of a wave inside the traversal loop (0 elsewhere)
-#endif
-
-#ifndef RTMI_ASM_WALK
-#define RTMI_ASM_WALK 1 // 0: the compiler's node step everywhere (the A/B and the fallback for a changed register budget)
-#endif
-static_assert(!RTMI_ASM_WALK || RTMI_WPE <= 6, "the hand-written node loop uses v66-v79 as its node registers");
-
-// The node steps of the walk as hand-scheduled loops (gfx950 ISA), one per memory layout.  A loop runs node steps for as long as
-// the vote says "node" and more than `floor` lanes still walk, and returns the two counts of the trip it stopped at (the
-// caller breaks or runs the leaf step).  Same arithmetic, instruction for instruction, as the C++ node step in the kernel
-// (which stays the path of the STATS and RTMI_PROF variants) -- what is gone is the glue the structurizer puts around it:
-// ~72 instructions per trip instead of ~95, and every instruction of this loop costs (10 extra per trip: 3-4 % of the frame).
-//   48-byte node record: ctr[2][3] fp32 | half[2][3] fp16, rounded up on the host | child[2]
-//   v66-v69 = c0x c0y c0z c1x   v70-v73 = c1y c1z h0x|h0y h0z|h1x   v74-v77 = h1y|h1z ch0 ch1 -
-// v_fma_mix_f32 takes the fp16 half extents as they are (exact conversion inside the FMA: the same value as v_cvt_f32_f16 +
-// v_fma_f32, six instructions less per trip).  References are signed (nodes >= 0, leaves < -1, sentinel -1); one stack level =
-// `stride` bytes; the far child is stored above the top unconditionally and only counts when both boxes are hit.
-// Inline asm is not seen by the hazard recogniser: no VALU-written mask is read by a VALU here (every mask a v_cndmask reads
-// comes out of a scalar instruction), which is the one gfx950 hazard these sequences could meet.
-//
-// walk_nodes_hbm: trees that stay in HBM (config 4: 100k spheres), three 16-byte loads through L1 / L2 / Infinity Cache on an SGPR
-// base, 32-bit stack entries.
-// The first `ktop` nodes of the breadth-first numbering -- the levels every walk passes through -- are staged into LDS by every
-// workgroup (the same 48-byte records at LDS address nbase + 48 * cur): a trip reads them with three ds_read_b128 and only
-// the lanes below that top go to memory.  A node read through the vector-memory path costs the CU's address unit 16 cycles per
-// 16-byte instruction whatever the hit rate (rocprofv3, round 3: 73 % of its cycles on config 4; round 4 with 384 nodes staged:
-// vector-memory reads -45 % per frame together with the tighter pad, frame -3.8 % from the staging alone).
-DEV void walk_nodes_hbm(Trav& t, const uint4* nodes, uint32_t nbase, uint32_t ktop, uint32_t stride, int floor, int& n_leaf, int& n_node) {
-    int tmp;
-    uint64_t m_node, m_leaf, saved, hit0, hit1;
-    float x, y, z, tn0;
-    asm volatile(
-        "L_top_%=:\n\t"
-        "v_cmp_le_i32_e64 %[mnode], 0, %[cur]\n\t"
-        "v_cmp_gt_i32_e64 %[mleaf], -1, %[cur]\n\t"
-        "s_bcnt1_i32_b64 %[nnode], %[mnode]\n\t"
-        "s_bcnt1_i32_b64 %[nleaf], %[mleaf]\n\t"
-        "s_add_i32 %[tmp], %[nnode], %[nleaf]\n\t"
-        "s_cmp_le_i32 %[tmp], %[floor]\n\t"
-        "s_cbranch_scc1 L_exit_%=\n\t"
-        "s_cmp_gt_i32 %[nleaf], %[nnode]\n\t"
-        "s_cbranch_scc1 L_exit_%=\n\t"
-        "s_and_saveexec_b64 %[saved], %[mnode]\n\t"
-        "v_mul_u32_u24_e32 %[x], 48, %[cur]\n\t"
-        "v_cmp_gt_u32_e32 vcc, %[ktop], %[cur]\n\t"     // this lane's node is in the staged top
-        "s_and_saveexec_b64 %[hit0], vcc\n\t"
-        "s_cbranch_execz L_nolds_%=\n\t"
-        "v_add_u32_e32 %[y], %[nbase], %[x]\n\t"
-        "ds_read_b128 v[66:69], %[y]\n\t"
-        "ds_read_b128 v[70:73], %[y] offset:16\n\t"
-        "ds_read_b128 v[74:77], %[y] offset:32\n\t"
-        "L_nolds_%=:\n\t"
-        "s_andn2_b64 exec, %[hit0], vcc\n\t"
-        "s_cbranch_execz L_nomem_%=\n\t"
-        "global_load_dwordx4 v[66:69], %[x], %[nodes]\n\t"
-        "global_load_dwordx4 v[70:73], %[x], %[nodes] offset:16\n\t"
-        "global_load_dwordx4 v[74:77], %[x], %[nodes] offset:32\n\t"
-        "L_nomem_%=:\n\t"
-        "s_mov_b64 exec, %[hit0]\n\t"
-        "s_waitcnt vmcnt(2) lgkmcnt(2)\n\t"
-        "v_fma_f32 v66, v66, %[ix], %[ox]\n\t"      // tc0x
-        "v_fma_f32 v67, v67, %[iy], %[oy]\n\t"      // tc0y
-        "v_fma_f32 v68, v68, %[iz], %[oz]\n\t"      // tc0z
-        "v_fma_f32 v69, v69, %[ix], %[ox]\n\t"      // tc1x
-        "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t"
-        "v_fma_f32 v70, v70, %[iy], %[oy]\n\t"      // tc1y
-        "v_fma_f32 v71, v71, %[iz], %[oz]\n\t"      // tc1z
-        "v_fma_mix_f32 v78, v72, |%[ix]|, %[px] op_sel_hi:[1,0,0]\n\t"                  // th0x: the pad rides in the FMA of the half extent
-        "v_fma_mix_f32 v72, v72, |%[iy]|, %[py] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th0y
-        "v_fma_mix_f32 v79, v73, |%[iz]|, %[pz] op_sel_hi:[1,0,0]\n\t"                  // th0z
-        "v_fma_mix_f32 v73, v73, |%[ix]|, %[px] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th1x
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        "v_fma_mix_f32 v77, v74, |%[iy]|, %[py] op_sel_hi:[1,0,0]\n\t"                  // th1y
-        "v_fma_mix_f32 v74, v74, |%[iz]|, %[pz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th1z
-        "v_sub_f32_e32 %[x], v66, v78\n\t"          // box 0, near: max(x, y, max(z, 1e-4))
-        "v_sub_f32_e32 %[y], v67, v72\n\t"
-        "v_sub_f32_e32 %[z], v68, v79\n\t"
-        "v_max_f32_e32 %[z], 0x38d1b717, %[z]\n\t"
-        "v_max3_f32 %[tn0], %[x], %[y], %[z]\n\t"
-        "v_add_f32_e32 %[x], v66, v78\n\t"          // far: min(x, y, min(z, tbest))
-        "v_add_f32_e32 %[y], v67, v72\n\t"
-        "v_add_f32_e32 %[z], v68, v79\n\t"
-        "v_min_f32_e32 %[z], %[z], %[tbest]\n\t"
-        "v_min3_f32 %[x], %[x], %[y], %[z]\n\t"
-        "v_cmp_le_f32_e64 %[hit0], %[tn0], %[x]\n\t"
-        "v_sub_f32_e32 %[x], v69, v73\n\t"          // box 1
-        "v_sub_f32_e32 %[y], v70, v77\n\t"
-        "v_sub_f32_e32 %[z], v71, v74\n\t"
-        "v_max_f32_e32 %[z], 0x38d1b717, %[z]\n\t"
-        "v_max3_f32 v66, %[x], %[y], %[z]\n\t"      // tn1
-        "v_add_f32_e32 %[x], v69, v73\n\t"
-        "v_add_f32_e32 %[y], v70, v77\n\t"
-        "v_add_f32_e32 %[z], v71, v74\n\t"
-        "v_min_f32_e32 %[z], %[z], %[tbest]\n\t"
-        "v_min3_f32 %[x], %[x], %[y], %[z]\n\t"
-        "v_cmp_le_f32_e64 %[hit1], v66, %[x]\n\t"
-        "v_cmp_lt_f32_e32 vcc, v66, %[tn0]\n\t"     // nearer1
-        "s_orn2_b64 vcc, vcc, %[hit0]\n\t"
-        "s_and_b64 %[mleaf], %[hit1], vcc\n\t"      // take1 = hit1 & (!hit0 | nearer1): the nearer child first
-        "v_cndmask_b32_e64 %[x], v76, v75, %[mleaf]\n\t"   // the far child: take1 ? ch0 : ch1
-        "ds_write_b32 %[sp], %[x]\n\t"
-        "v_cndmask_b32_e64 %[cur], v75, v76, %[mleaf]\n\t" // take1 ? ch1 : ch0
-        "s_and_b64 vcc, %[hit0], %[hit1]\n\t"
-        "v_cndmask_b32_e32 %[y], 0, %[stride], vcc\n\t"
-        "v_add_u32_e32 %[sp], %[sp], %[y]\n\t"
-        "s_or_b64 vcc, %[hit0], %[hit1]\n\t"
-        "s_andn2_b64 exec, exec, vcc\n\t"           // neither box hit: pop
-        "s_cbranch_execz L_nopop_%=\n\t"
-        "v_sub_u32_e32 %[sp], %[sp], %[stride]\n\t"
-        "ds_read_b32 %[cur], %[sp]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "L_nopop_%=:\n\t"
-        "s_mov_b64 exec, %[saved]\n\t"
-        "s_branch L_top_%=\n\t"
-        "L_exit_%=:"
-        : [cur] "+v"(t.cur), [sp] "+v"(t.sp), [nleaf] "=&s"(n_leaf), [nnode] "=&s"(n_node), [tmp] "=&s"(tmp),
-          [mnode] "=&s"(m_node), [mleaf] "=&s"(m_leaf), [saved] "=&s"(saved), [hit0] "=&s"(hit0), [hit1] "=&s"(hit1),
-          [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [tn0] "=&v"(tn0)
-        : [ix] "v"(t.inv.x), [iy] "v"(t.inv.y), [iz] "v"(t.inv.z), [ox] "v"(t.oinv.x), [oy] "v"(t.oinv.y),
-          [oz] "v"(t.oinv.z), [px] "v"(t.pinv.x), [py] "v"(t.pinv.y), [pz] "v"(t.pinv.z), [tbest] "v"(t.tbest),
-          [stride] "v"(stride), [nodes] "s"(nodes), [nbase] "s"(nbase), [ktop] "s"(ktop), [floor] "s"(floor)
-        : "vcc", "scc", "memory", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
-          "v78", "v79");
-}
-
-// walk_nodes_lds: trees staged into LDS whole (up to 8192 spheres), the same record at LDS address nbase + 48 * cur, 16-bit
-// stack entries.  Rounds 1-3 kept 64-byte all-fp32 records here: four reads per trip and a stride of 16 dwords that put every
-// read of a trip on 16 of the 64 banks.  A/B on MI355X (S-RTOW 1080p x 128 spp, profiles/r04_lds_node_layout.txt):
-// SQ_LDS_BANK_CONFLICT 2.39 G -> 1.06 G (27 % -> 15 % of SQ_LDS_IDX_ACTIVE, itself -20 %), SQ_WAIT_INST_LDS -25 %, LDS
-// 73.5 -> 68.9 KB per workgroup -- and the frame time unchanged within 0.2 %: the walk never waited on the banks.
-DEV void walk_nodes_lds(Trav& t, uint32_t nbase, uint32_t stride, int floor, int& n_leaf, int& n_node) {
-    int tmp;
-    uint64_t m_node, m_leaf, saved, hit0, hit1;
-    float x, y, z, tn0;
-    asm volatile(
-        "L_top_%=:\n\t"
-        "v_cmp_le_i32_e64 %[mnode], 0, %[cur]\n\t"
-        "v_cmp_gt_i32_e64 %[mleaf], -1, %[cur]\n\t"
-        "s_bcnt1_i32_b64 %[nnode], %[mnode]\n\t"
-        "s_bcnt1_i32_b64 %[nleaf], %[mleaf]\n\t"
-        "s_add_i32 %[tmp], %[nnode], %[nleaf]\n\t"
-        "s_cmp_le_i32 %[tmp], %[floor]\n\t"
-        "s_cbranch_scc1 L_exit_%=\n\t"
-        "s_cmp_gt_i32 %[nleaf], %[nnode]\n\t"
-        "s_cbranch_scc1 L_exit_%=\n\t"
-        "s_and_saveexec_b64 %[saved], %[mnode]\n\t"
-        "v_mad_u32_u24 %[x], %[cur], 48, %[nbase]\n\t"
-        "ds_read_b128 v[66:69], %[x]\n\t"
-        "ds_read_b128 v[70:73], %[x] offset:16\n\t"
-        "ds_read_b128 v[74:77], %[x] offset:32\n\t"
-        "s_waitcnt lgkmcnt(2)\n\t"
-        "v_fma_f32 v66, v66, %[ix], %[ox]\n\t"      // tc0x
-        "v_fma_f32 v67, v67, %[iy], %[oy]\n\t"      // tc0y
-        "v_fma_f32 v68, v68, %[iz], %[oz]\n\t"      // tc0z
-        "v_fma_f32 v69, v69, %[ix], %[ox]\n\t"      // tc1x
-        "s_waitcnt lgkmcnt(1)\n\t"
-        "v_fma_f32 v70, v70, %[iy], %[oy]\n\t"      // tc1y
-        "v_fma_f32 v71, v71, %[iz], %[oz]\n\t"      // tc1z
-        "v_fma_mix_f32 v78, v72, |%[ix]|, %[px] op_sel_hi:[1,0,0]\n\t"                  // th0x: the pad rides in the FMA of the half extent
-        "v_fma_mix_f32 v72, v72, |%[iy]|, %[py] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th0y
-        "v_fma_mix_f32 v79, v73, |%[iz]|, %[pz] op_sel_hi:[1,0,0]\n\t"                  // th0z
-        "v_fma_mix_f32 v73, v73, |%[ix]|, %[px] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th1x
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_fma_mix_f32 v77, v74, |%[iy]|, %[py] op_sel_hi:[1,0,0]\n\t"                  // th1y
-        "v_fma_mix_f32 v74, v74, |%[iz]|, %[pz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"   // th1z
-        "v_sub_f32_e32 %[x], v66, v78\n\t"          // box 0, near: max(x, y, max(z, 1e-4))
-        "v_sub_f32_e32 %[y], v67, v72\n\t"
-        "v_sub_f32_e32 %[z], v68, v79\n\t"
-        "v_max_f32_e32 %[z], 0x38d1b717, %[z]\n\t"
-        "v_max3_f32 %[tn0], %[x], %[y], %[z]\n\t"
-        "v_add_f32_e32 %[x], v66, v78\n\t"          // far: min(x, y, min(z, tbest))
-        "v_add_f32_e32 %[y], v67, v72\n\t"
-        "v_add_f32_e32 %[z], v68, v79\n\t"
-        "v_min_f32_e32 %[z], %[z], %[tbest]\n\t"
-        "v_min3_f32 %[x], %[x], %[y], %[z]\n\t"
-        "v_cmp_le_f32_e64 %[hit0], %[tn0], %[x]\n\t"
-        "v_sub_f32_e32 %[x], v69, v73\n\t"          // box 1
-        "v_sub_f32_e32 %[y], v70, v77\n\t"
-        "v_sub_f32_e32 %[z], v71, v74\n\t"
-        "v_max_f32_e32 %[z], 0x38d1b717, %[z]\n\t"
-        "v_max3_f32 v66, %[x], %[y], %[z]\n\t"      // tn1
-        "v_add_f32_e32 %[x], v69, v73\n\t"
-        "v_add_f32_e32 %[y], v70, v77\n\t"
-        "v_add_f32_e32 %[z], v71, v74\n\t"
-        "v_min_f32_e32 %[z], %[z], %[tbest]\n\t"
-        "v_min3_f32 %[x], %[x], %[y], %[z]\n\t"
-        "v_cmp_le_f32_e64 %[hit1], v66, %[x]\n\t"
-        "v_cmp_lt_f32_e32 vcc, v66, %[tn0]\n\t"     // nearer1
-        "s_orn2_b64 vcc, vcc, %[hit0]\n\t"
-        "s_and_b64 %[mleaf], %[hit1], vcc\n\t"      // take1 = hit1 & (!hit0 | nearer1): the nearer child first
-        "v_cndmask_b32_e64 %[x], v76, v75, %[mleaf]\n\t"   // the far child: take1 ? ch0 : ch1
-        "ds_write_b16 %[sp], %[x]\n\t"
-        "v_cndmask_b32_e64 %[cur], v75, v76, %[mleaf]\n\t" // take1 ? ch1 : ch0
-        "s_and_b64 vcc, %[hit0], %[hit1]\n\t"
-        "v_cndmask_b32_e32 %[y], 0, %[stride], vcc\n\t"
-        "v_add_u32_e32 %[sp], %[sp], %[y]\n\t"
-        "s_or_b64 vcc, %[hit0], %[hit1]\n\t"
-        "s_andn2_b64 exec, exec, vcc\n\t"           // neither box hit: pop
-        "s_cbranch_execz L_nopop_%=\n\t"
-        "v_sub_u32_e32 %[sp], %[sp], %[stride]\n\t"
-        "ds_read_i16 %[cur], %[sp]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "L_nopop_%=:\n\t"
-        "s_mov_b64 exec, %[saved]\n\t"
-        "s_branch L_top_%=\n\t"
-        "L_exit_%=:"
-        : [cur] "+v"(t.cur), [sp] "+v"(t.sp), [nleaf] "=&s"(n_leaf), [nnode] "=&s"(n_node), [tmp] "=&s"(tmp),
-          [mnode] "=&s"(m_node), [mleaf] "=&s"(m_leaf), [saved] "=&s"(saved), [hit0] "=&s"(hit0), [hit1] "=&s"(hit1),
-          [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [tn0] "=&v"(tn0)
-        : [ix] "v"(t.inv.x), [iy] "v"(t.inv.y), [iz] "v"(t.inv.z), [ox] "v"(t.oinv.x), [oy] "v"(t.oinv.y),
-          [oz] "v"(t.oinv.z), [px] "v"(t.pinv.x), [py] "v"(t.pinv.y), [pz] "v"(t.pinv.z), [tbest] "v"(t.tbest),
-          [stride] "v"(stride), [nbase] "s"(nbase), [floor] "s"(floor)
-        : "vcc", "scc", "memory", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
-          "v78", "v79");
-}
-
-// BIG = false: the whole scene is staged into LDS and stack entries are packed into 16 bits (<= 8192 spheres).
-// BIG = true : the scene stays in HBM (read through L1/L2/Infinity Cache), only the traversal stack is in LDS,
-//              32-bit entries (config 4: 100k spheres, 2.4 MB of spheres + 6.4 MB of nodes).
-template <int ACCEL, bool STATS, bool BIG, int MODE>
-// 6 waves per SIMD (<= 80 VGPRs): two workgroups of 768 lanes per CU; that occupancy is worth +17 % over 4 waves per
-// SIMD (measured), and one register more would silently halve it -- hence the explicit bound
-// (HBM-resident scenes wait on their node reads, not on issue slots: their variants are allocated for 8 waves per SIMD --
-// 64 VGPRs, which they fit without spilling -- and run as two 896-lane workgroups per CU, 7 waves per SIMD: -3.4 %)
-__global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE, BIG ? RTMI_WPE_BIG : RTMI_WPE))) __launch_bounds__(1024) rtmi_trace_kernel(const RtmiLaunch P) {
-    // MODE 0: work items are chunks of a pixel's samples, one 16-byte record per sample; 3: whole-pixel work items (no
-    // sample records: the lane adds its pixel's samples up itself); 4: as 0, with the attenuation chain as a packed string
-    // of material handles in LDS that leaves with the sample record and is multiplied by the resolve pass (scenes whose
-    // strings fit the LDS: few materials or a low bounce limit; the box of config 5).  (Modes 1 / 2, the deferred-path
-    // queue and its drain launch of rounds 1-2, were measured 8 % slower on the final round-2 kernel and are gone.)
-    constexpr bool WHOLE = MODE == 3, PACKED = MODE == 4;
-    static_assert(!(PACKED && BIG), "packed chains live next to an LDS-resident scene");
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    using StackT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
-    // traversal stack: entry 0 of every lane holds a sentinel that ends the walk when it is popped.  References are
-    // signed: nodes >= 0, leaves < -1, the sentinel -1 (16-bit entries are read back sign-extended); t.sp is an LDS address
-    using StackS = typename std::conditional<BIG, int32_t, int16_t>::type;
-    typedef __attribute__((address_space(3))) StackS lds_stack_t;
-    constexpr uint32_t kStackEnd = 0xffffffffu;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8*)lds_raw;
-    const uint32_t sp0 = lds0 + P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT), sp_stride = blockDim.x * (uint32_t)sizeof(StackT);
-    auto stack_at = [](uint32_t addr) -> lds_stack_t* { return (lds_stack_t*)(uintptr_t)addr; };
-    if (ACCEL == RTMI_ACCEL_BVH) *stack_at(sp0) = (StackS)-1;
-    uint32_t* lds_att = reinterpret_cast<uint32_t*>(lds_raw + P.lds_att);
-    // per-wave pools: work indices are taken from the global counter 64 at a time (a single counter word saturates at
-    // ~88 returning atomics per microsecond on MI355X; a 1080p x 512 spp frame has 16.6 M work items)
-    uint32_t* pool = reinterpret_cast<uint32_t*>(lds_raw + P.lds_pool) + (threadIdx.x >> 6) * 20u;
-    lds_u8* rank_tbl = (lds_u8*)(pool + 4); // 64 bytes, see coop_draws
-    if ((threadIdx.x & 63u) == 0u) {
-        pool[0] = 0u; pool[1] = 0u; pool[2] = 0u; pool[3] = 0u;
-    }
-    const uint4* lds_spheres;
-    const uint4* lds_aux;
-    const uint4* lds_mats;
-    const uint4* lds_nodes;
-    if (BIG) {
-        // the scene stays in memory; the first lds_top_nodes nodes of the breadth-first numbering (48-byte records) start the
-        // dynamic LDS segment and the node step reads them from there (walk_nodes_hbm)
-        lds_spheres = P.spheres;
-        lds_aux = P.aux;
-        lds_mats = P.mats;
-        lds_nodes = P.nodes;
-        if (ACCEL == RTMI_ACCEL_BVH && P.lds_top_nodes != 0u) {
-            uint4* w_nodes = reinterpret_cast<uint4*>(lds_raw);
-            for (uint32_t i = threadIdx.x; i < 3u * P.lds_top_nodes; i += blockDim.x) w_nodes[i] = P.nodes[i];
-            __syncthreads();
-        }
-    } else {
-        // ---- stage the scene into LDS: coalesced 16-byte loads, one pass per array -------------------------
-        uint4* w_spheres = reinterpret_cast<uint4*>(lds_raw + P.lds_spheres);
-        uint4* w_aux = reinterpret_cast<uint4*>(lds_raw + P.lds_aux);
-        uint4* w_mats = reinterpret_cast<uint4*>(lds_raw + P.lds_mats);
-        uint4* w_nodes = reinterpret_cast<uint4*>(lds_raw); // nodes always start the dynamic LDS segment
-        for (uint32_t i = threadIdx.x; i < P.n_slots; i += blockDim.x) {
-            w_spheres[i] = P.spheres[i];
-            w_aux[i] = P.aux[i];
-        }
-        for (uint32_t i = threadIdx.x; i < P.n_mats; i += blockDim.x) w_mats[i] = P.mats[i];
-        if (ACCEL == RTMI_ACCEL_BVH) {
-            for (uint32_t i = threadIdx.x; i < 3u * P.n_nodes; i += blockDim.x) w_nodes[i] = P.nodes[i];
-        }
-        __syncthreads();
-        lds_spheres = w_spheres;
-        lds_aux = w_aux;
-        lds_mats = w_mats;
-        lds_nodes = w_nodes;
-    }
-
-#ifdef RTMI_TAILPROBE
-    const uint32_t tp_wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if ((threadIdx.x & 63u) == 0u && P.tail_probe) { P.tail_probe[3u * tp_wave] = wall_clock64(); P.tail_probe[3u * tp_wave + 1u] = 0ull; }
-#endif
-    // (functions, not values: these are needed once per path or per launch and must not hold a register in between)
-    auto glane_of = [&]() -> uint32_t { return blockIdx.x * blockDim.x + threadIdx.x; };
-#define glane glane_of()
-#define lane lane_id()
-    const uint32_t W = P.cam.img_width;
-    const uint32_t spp = P.cam.samples_per_pixel;
-
-    uint32_t phase = PH_FETCH;
-    uint32_t lpix = 0, s = 0, s_end = 0, depth_left = 0, natt = 0; // lpix: pixel index within this call's rows
-    V3 sum = mk(0.0f, 0.0f, 0.0f); // WHOLE only: the pixel's running sum
-    Rng rng{};
-    Trav t{};
-    t.cur = kStackEnd; // "not walking" (see the traversal loop)
-    uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0, st_item0 = 0;
-    uint32_t parked = 0; // packed-chain launches: a primary ray for this lane's next sample is in its LDS slot (GEN phase)
-    PF_DECL
-    PB_DECL
-
-    // attenuation chain: material handles of the non-dielectric bounces of the live path, run-length encoded (a path
-    // trapped inside the ground sphere bounces 50 times on the same material: one run).  The open run lives in two
-    // registers, closed runs in LDS (kAttLds per lane, {handle, count} packed in 32 bits); only a path with more than
-    // kAttLds material changes spills to a per-lane strip in HBM.  rocprofv3 on the un-encoded chain: 90 GB of
-    // write-backs per 1080p x 512 spp frame, all of it this strip.
-    const uint32_t maxdepth = P.cam.maxdepth;
-    uint32_t run_h = 0, run_n = 0;
-    // LDS-resident scenes: closed runs go through a window of kAttLds (4) entries in LDS; a full window leaves as ONE
-    // 16-byte store to the lane's strip in HBM, so a path whose material changes at every bounce (the box of config 5:
-    // 79 segments per sample) moves 4 bytes per bounce instead of the two lone 4-byte stores it used to cost
-    // (rocprofv3 on config 5: 2.4 TB of write-backs per frame before).
-    const uint32_t att_blocks = (maxdepth + 3u) >> 2;
-    auto att_store = [&](uint32_t q, uint32_t h, uint32_t n) {
-        if (!BIG) {
-            const uint32_t e = h | (n << 16);
-            const uint32_t j = q & 3u;
-            lds_att[j * blockDim.x + threadIdx.x] = e;
-            if (j == 3u) {
-                reinterpret_cast<uint4*>(P.att_stack)[(size_t)glane * att_blocks + (q >> 2)] =
-                    make_uint4(lds_att[threadIdx.x], lds_att[blockDim.x + threadIdx.x], lds_att[2u * blockDim.x + threadIdx.x], e);
-            }
-        } else {
-            P.att_stack[((size_t)glane * maxdepth + q) * 2u] = h;
-            P.att_stack[((size_t)glane * maxdepth + q) * 2u + 1u] = n;
-        }
-    };
-    // MODE 4 keeps the chain as a string of handles instead: run_h = the word being filled, run_n = bits used in it |
-    // index of that word << 8, natt = handles so far.  A path of the config-5 box changes material at nearly every one
-    // of its 79 bounces: run-length encoding buys nothing there, the strips it spilled to were 27x the algorithmic HBM
-    // traffic of the launch (r02 profile) and the multiplication at the end of a path ran for one or two lanes of a wave
-    // at a time.  Here the string stays in LDS while the path lives, leaves in 16-byte stores next to the sample record
-    // when the path reaches the sky, and the resolve pass -- one lane per pixel, every lane busy -- does the multiplying.
-    auto att_push = [&](uint32_t h) {
-        if (PACKED) {
-            run_h |= h << (run_n & 255u);
-            run_n += P.att_bits;
-            natt++;
-            if ((run_n & 255u) + P.att_bits > 32u) { // no room for another handle: the word goes to LDS
-                lds_att[(run_n >> 8) * blockDim.x + threadIdx.x] = run_h;
-                run_h = 0u;
-                run_n = (run_n & ~255u) + 256u;
-            }
-            return;
-        }
-        if (run_n != 0u && h == run_h) {
-            run_n++;
-        } else {
-            if (run_n != 0u) att_store(natt++, run_h, run_n);
-            run_h = h;
-            run_n = 1u;
-        }
-    };
-    auto att_apply = [&](V3 color, uint32_t h, uint32_t n) -> V3 {
-        const uint4 m0 = lds_mats[h];
-        const V3 a = mk(__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z));
-        for (uint32_t c = 0; c < n; ++c) color = vmul(a, color); // A*(A*(...)): one multiply per bounce, in order
-        return color;
-    };
-    // the spheres of one leaf against the current segment, two at a time: both discriminants, then the (rare) roots.
-    // The first pair is straight code -- with the default leaf size of 2 it is the whole leaf -- larger leaves loop on
-    auto test_leaf = [&](uint32_t ref) {
-        const uint32_t first = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
-        const uint32_t cnt = BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u);
-        t.a = vdot(t.d, t.d); // (recomputed here: not a register across the node steps)
-        const Recip ra = recip_for(t.a); // shared by every root of this leaf step
-        auto pair = [&](uint32_t q) {
-            const bool two = q + 1u < cnt;
-            const uint4 r0 = lds_spheres[first + q];
-            const uint4 r1 = lds_spheres[first + q + (two ? 1u : 0u)];
-            float h0, h1, d0, d1;
-            bool k0, k1;
-            sphere_delta_cand(r0, t, h0, d0, k0);
-            sphere_delta_cand(r1, t, h1, d1, k1);
-            k1 = k1 & two;
-            // Roots only for spheres that can have one ahead of the origin (sphere_delta_cand), and ONE pass of the root
-            // arithmetic for the lanes' first such sphere, whichever of the two it is: with a separate branch per sphere the wave
-            // ran both (~45 instructions each) whenever any lane needed either -- nearly every leaf trip -- although hardly a lane
-            // needs both; the second pass is left for the trips in which one does.  Per lane the spheres are still taken in slot
-            // order (and ties go by object index, sphere_root_bvh): the closest hit is the same.
-            if (k0 | k1) {
-                const bool sec = !k0;
-                sphere_root_bvh(sec ? h1 : h0, sec ? d1 : d0, t, ra, first + q + (sec ? 1u : 0u), lds_aux, t.tbest, t.best);
-                if (k0 & k1) sphere_root_bvh(h1, d1, t, ra, first + q + 1u, lds_aux, t.tbest, t.best);
-            }
-        };
-        pair(0u);
-        if (cnt > 2u) {
-            for (uint32_t q = 2u; q < cnt; q += 2u) pair(q);
-        }
-        if (STATS) st_sphere += cnt;
-    };
-    auto begin_segment = [&](V3 o, V3 d) {
-        t.o = o;
-        t.d = d;
-        t.a = vdot(d, d);
-        t.tbest = __builtin_inff();
-        t.best = ~0u;
-        t.sp = lds0 + P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT) + sp_stride; // entry 1 (entry 0: the sentinel)
-        if (ACCEL == RTMI_ACCEL_BVH) {
-            t.cur = P.root_ref;
-            t.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-            PF_MARK(17);
-            t.oinv = mk(-(o.x * t.inv.x), -(o.y * t.inv.y), -(o.z * t.inv.z));
-            // Leaves that hang directly off the top of the tree -- the ground sphere, whose box is the whole scene; the
-            // walls of a box made of huge spheres -- are tested here, by all the lanes that start a segment, and the
-            // walk begins below them with the far limit already set: one node trip and one leaf trip less per leaf
-            // and segment.  A tree that is nothing but such a spine is not walked at all.
-            for (uint32_t q = 0; q < P.n_pre_leaves; ++q) {
-                const uint32_t ref = P.pre_leaf[q]; // wave-uniform
-                const uint32_t cnt = BIG ? ((ref >> 24) & 0x7fu) : (((ref >> 13) & 3u) + 1u);
-                if (cnt == 1u) { // a lone sphere (the ground): one discriminant, not the pair routine's two
-                    const uint32_t slot = BIG ? (ref & 0x00ffffffu) : (ref & 0x1fffu);
-                    float h0, d0;
-                    bool k0;
-                    sphere_delta_cand(lds_spheres[slot], t, h0, d0, k0);
-                    if (k0) sphere_root_bvh(h0, d0, t, recip_for(t.a), slot, lds_aux, t.tbest, t.best);
-                    if (STATS) st_sphere += 1u;
-                } else {
-                    test_leaf(ref);
-                }
-            }
-            PF_MARK(18);
-            // The pad of this segment's boxes: every sphere whose root the reference's fp32 arithmetic could
-            // accept must be reached.  Per radius class, E0 = e(farthest centre of the class) bounds it for any ray from this
-            // origin; on scenes much wider than their spheres (pad_refine: the 316-unit grid of config 4, where E0 is 0.1-0.8
-            // units on spheres of radius 0.2) the segment's reach bounds it far better: an accepted root's point lies within
-            // G = rmax + E0 of a centre, hence inside the class's centre box grown by G, and before the far limit the peeled
-            // leaves left (the ground hit), so L <= t_far |d| + G and E1 = e(L_max) -- the same expression in the oracle's walk.
-            float pad = P.pad_floor;
-            if (P.pad_refine) pad = fmaxf(pad, 9.5367432e-7f * fmaxf(fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z))); // 16u |O|_inf
-            const float pad_floor_o = pad;
-            const float dlen = P.pad_refine ? __builtin_amdgcn_sqrtf(t.a) * 1.00001f : 0.0f;
-            for (uint32_t c = 0; c < P.n_pad_classes; ++c) {
-                const float* k = P.pad_classes[c];
-                const float ax = fmaxf((o.x - k[0]) * (o.x - k[0]), (k[3] - o.x) * (k[3] - o.x));
-                const float ay = fmaxf((o.y - k[1]) * (o.y - k[1]), (k[4] - o.y) * (k[4] - o.y));
-                const float az = fmaxf((o.z - k[2]) * (o.z - k[2]), (k[5] - o.z) * (k[5] - o.z));
-                // sqrt(R^2 + x) - R <= min(x / (2R), sqrt(x)): the linear bound explodes for a ray that starts thousands of
-                // units away (a path inside the ground sphere), the square root does not
-                const float x = P.pad_eps * (((ax + ay) + az) + k[7]); // k[7]: rmax^2 of the class
-                float ec = fminf(x * k[6], __builtin_amdgcn_sqrtf(x) * 1.000001f);
-                if (P.pad_refine) {
-                    // (twice the floor on top of the reach: the exit parameters below are off by at most ~3u (|plane| + |O|) |1/d|)
-                    const float g = __builtin_fmaf(2.0f, pad_floor_o, P.pad_rmax[c] + ec);
-                    const float ex = fmaxf(__builtin_fmaf(k[0] - g, t.inv.x, t.oinv.x), __builtin_fmaf(k[3] + g, t.inv.x, t.oinv.x));
-                    const float ey = fmaxf(__builtin_fmaf(k[1] - g, t.inv.y, t.oinv.y), __builtin_fmaf(k[4] + g, t.inv.y, t.oinv.y));
-                    const float ez = fmaxf(__builtin_fmaf(k[2] - g, t.inv.z, t.oinv.z), __builtin_fmaf(k[5] + g, t.inv.z, t.oinv.z));
-                    // (fmaxf / fminf drop a NaN operand -- 0 * inf on an axis-parallel ray: that axis does not bound the reach)
-                    const float t_far = fmaxf(fminf(fminf(ex, ey), fminf(ez, t.tbest)), 0.0f);
-                    const float lmax = __builtin_fmaf(t_far, dlen, g);
-                    const float x1 = P.pad_eps * (lmax * lmax + k[7]);
-                    ec = fminf(ec, fminf(x1 * k[6], __builtin_amdgcn_sqrtf(x1) * 1.000001f));
-                }
-                pad = fmaxf(pad, ec);
-            }
-            t.pinv = mk(pad * __builtin_fabsf(t.inv.x), pad * __builtin_fabsf(t.inv.y), pad * __builtin_fabsf(t.inv.z));
-            PF_MARK(19);
-        } else {
-            t.cur = 0; // next sphere of the linear scan
-        }
-        if (STATS) st_segments++;
-    };
-
-    for (;;) {
-        PF_MARK(16);
-        // ---- FETCH: one wave-aggregated atomic hands out consecutive indices of the 8x8-tiled pixel space -----
-        ISA_MARK("fetch");
-        PB(21, true);
-        PB(0, phase == PH_FETCH);
-        while (phase == PH_FETCH) {
-            const uint64_t need = ballot(true);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            uint32_t start = 0, take = 0, txy = 0, s_first = 0;
-            if (rank == 0) { // the wave's leader serves the request from the wave's pool, refilling it 64 items at a time
-                uint32_t next = pool[0], end = pool[1];
-                if (next == end) {
-                    next = atomicAdd(P.work_counter, 64u);
-                    end = next + 64u;
-                    pool[1] = end;
-                    // a refill is one unit of 64 consecutive indices: the 64 pixels of ONE 8x8 tile for ONE chunk of samples, so
-                    // the tile is looked up here, once per 64 items, and travels to the lanes with the indices.  Hand-out position
-                    // -> tile through the launch's order table (costliest tiles first: the heavy-tailed items -- pixels of the
-                    // horizon band, most of whose samples run all 50 bounces inside the ground sphere -- start when the launch
-                    // does, and its end is made of sky), or row by row, bottom rows first.
-#ifdef RTMI_TAILPROBE
-                    if (next >= P.n_work && P.tail_probe && P.tail_probe[3u * tp_wave + 1u] == 0ull) P.tail_probe[3u * tp_wave + 1u] = wall_clock64();
-#endif
-                    const uint32_t unit = next >> 6;
-                    const uint32_t pos = fdiv(unit, P.div_chunks);
-                    const uint32_t s0 = (unit - pos * P.n_chunks) * P.chunk; // the item's first sample
-                    uint32_t tile = pos, flip = P.top_down ? 0u : 1u;
-                    if (P.tile_order != nullptr && next < P.n_work) {
-                        tile = P.tile_order[pos];
-                        flip = 0u;
-                    }
-                    const uint32_t trow = fdiv(tile, P.div_tiles_x);
-                    pool[2] = (tile - trow * P.tiles_x) | ((flip ? P.tiles_y - 1u - trow : trow) << 16);
-                    pool[3] = s0;
-                }
-                take = min((uint32_t)__popcll(need), end - next);
-                start = next;
-                pool[0] = next + take;
-                txy = pool[2];
-                s_first = pool[3];
-            }
-            const int leader = __ffsll((long long)need) - 1;
-            start = __shfl(start, leader);
-            take = __shfl(take, leader);
-            txy = __shfl(txy, leader);
-            s_first = __shfl(s_first, leader);
-            if (rank >= take) continue; // pool ran dry mid-request: ask again
-            const uint32_t idx = start + rank;
-            if (idx >= P.n_work) {
-                phase = PH_DONE;
-            } else {
-                const uint32_t j = idx & 63u;
-                const uint32_t px = P.x_first + (txy & 0xffffu) * 8u + (j & 7u), ply = (txy >> 16) * 8u + (j >> 3);
-                if (px < P.x_end && ply < P.n_local_rows) {
-                    const uint32_t blk = fdiv(ply, P.div_block_rows); // local row -> row of the whole image
-                    const uint32_t gy = P.y_first + blk * P.block_stride * P.block_rows + (ply - blk * P.block_rows);
-                    lpix = ply * P.local_w + (px - P.x_first);
-                    rng.pixel = gy * W + px;
-                    s = s_first;
-                    s_end = min(spp, s + P.chunk);
-                    if (WHOLE) sum = mk(0.0f, 0.0f, 0.0f);
-                    phase = PH_GEN;
-                }
-            }
-        }
-        if (ballot(phase != PH_DONE) == 0ull) break;
-        PF_MARK(0);
-
-        // ---- GEN: RayTracingCore::get_ray, core.cc:218-234 --------------------------------------------------------
-        ISA_MARK("gen");
-        PB(1, phase == PH_GEN);
-        // (a gate on this branch -- run it only when K lanes need a primary ray or one has waited T rounds -- was measured
-        // on configs 3, 4 and 5: +-0 at best, slower from K = 8 up; profiles/r03_gating_experiment.txt)
-        // RayTracingCore::get_ray for sample `gs` of this lane's pixel: the two defocus-disk offsets, the direction pixel_sample - origin
-        // and the stream position behind the draws it took (nothing of the lane's live path state is touched)
-        auto gen_ray = [&](uint32_t gs, float& dx, float& dy, V3& dir, uint32_t& k_after) {
-            const uint32_t gy = fdiv(rng.pixel, P.div_w), px = rng.pixel - gy * W; // (rng.pixel = gy * W + px came with the work item)
-            Rng r2;
-            r2.pixel = rng.pixel;
-            r2.sample = gs;
-            r2.k = 2;
-            Blk gb = rng_block(r2, 0u, P.seed); // draws 0,1: pixel jitter; 2,3: first defocus-disk attempt
-            const float offx = draw_centered(gb.w0);
-            const float offy = draw_centered(gb.w1);
-            const V3 du = ld3(P.cam.pixel_delta_u), dv = ld3(P.cam.pixel_delta_v);
-            const V3 pixel_sample =
-                vadd(vadd(ld3(P.cam.pixel00), vscale(du, (float)px + offx)), vscale(dv, (float)gy + offy));
-            V3 origin = ld3(P.cam.cam_center);
-            dx = 0.0f;
-            dy = 0.0f;
-            if (!(P.cam.defocus_angle <= 0.0f)) {
-                // random_vector_on_unit_disk, random.number.gen.hpp:35-42
-                dx = draw_pm1(gb.w2);
-                dy = draw_pm1(gb.w3);
-                r2.k = 4;
-                ISA_MARK("gen-disk-retry");
-                PF_MARK(1);
-                while (!(vdot(mk(dx, dy, 0.0f), mk(dx, dy, 0.0f)) < 1.0f)) { // two attempts per further block
-                    PB(2, true);
-                    if ((r2.k & 3u) == 0u) gb = rng_block(r2, r2.k >> 2, P.seed);
-                    dx = draw_pm1((r2.k & 3u) ? gb.w2 : gb.w0);
-                    dy = draw_pm1((r2.k & 3u) ? gb.w3 : gb.w1);
-                    r2.k += 2u;
-                }
-                PF_MARK(20);
-                ISA_MARK("gen-tail");
-                origin = vadd(vadd(ld3(P.cam.cam_center), vscale(ld3(P.cam.defocus_disk_u), dx)),
-                              vscale(ld3(P.cam.defocus_disk_v), dy));
-            }
-            dir = vsub(pixel_sample, origin);
-            k_after = r2.k;
-        };
-        // the lens point of get_ray from its two offsets (core.cc:226-231)
-        auto ray_origin = [&](float dx, float dy) -> V3 {
-            V3 origin = ld3(P.cam.cam_center);
-            if (!(P.cam.defocus_angle <= 0.0f))
-                origin = vadd(vadd(ld3(P.cam.cam_center), vscale(ld3(P.cam.defocus_disk_u), dx)), vscale(ld3(P.cam.defocus_disk_v), dy));
-            return origin;
-        };
-        auto start_sample = [&](float dx, float dy, V3 dir, uint32_t k_after) {
-            rng.k = k_after;
-            depth_left = P.cam.maxdepth;
-            natt = 0;
-            run_n = 0;
-            if (PACKED) run_h = 0;
-            if (depth_left == 0) {
-                // compute_color(depth == 0) returns 0 at once (core.cc:238-240): the sample is black
-                t.best = kBlackSample; // marker read by SHADE: finish the sample without tracing
-                phase = PH_SHADE;
-            } else {
-                t.o = ray_origin(dx, dy);
-                t.d = dir;
-                phase = PH_BEGIN;
-            }
-        };
-        if (PACKED && P.lds_ahead != 0u) {
-            // Primary rays generated ahead (packed-chain launches whose LDS has room for the slots: the box of config 5, where this
-            // branch -- ~130 instructions -- ran in every other round for ONE or two lanes: 79 segments to a sample, 64 lanes).  A
-            // primary ray is a pure function of (pixel, sample): whenever some lane has to generate one NOW, every lane that is
-            // inside a sample and has none in store generates the ray of its item's NEXT sample alongside and parks it -- lens
-            // offsets, direction, stream position: 21 bytes of LDS a lane -- and a lane that starts a sample with a ray in store
-            // takes it.  Round 4 measured it (+1.6 % on the box, bit-identical) and did not ship it because the S-RTOW scene has no
-            // room for the slots; it is a per-variant switch now (VERDICT r4 #3a).
-            float* slot = reinterpret_cast<float*>(lds_raw + P.lds_ahead) + threadIdx.x;
-            lds_u8* kslot = (lds_u8*)(uintptr_t)(lds0 + P.lds_ahead + 20u * blockDim.x + threadIdx.x);
-            const bool now = phase == PH_GEN && parked == 0u;
-            if (ballot(now) != 0ull) {
-                const bool ahead = parked == 0u && (phase == PH_BEGIN || phase == PH_TRAV || phase == PH_SHADE) && s + 1u < s_end;
-                if (now || ahead) {
-                    float dx, dy;
-                    V3 dir;
-                    uint32_t k_after;
-                    gen_ray(now ? s : s + 1u, dx, dy, dir, k_after);
-                    if (now) {
-                        start_sample(dx, dy, dir, k_after);
-                    } else {
-                        slot[0] = dx;
-                        slot[blockDim.x] = dy;
-                        slot[2u * blockDim.x] = dir.x;
-                        slot[3u * blockDim.x] = dir.y;
-                        slot[4u * blockDim.x] = dir.z;
-                        *kslot = (uint8_t)k_after;
-                        parked = k_after > 255u ? 0u : 1u; // (a stream position past 255 -- 125 rejected disk points in a row -- is not parked)
-                    }
-                }
-            }
-            if (phase == PH_GEN && parked != 0u) {
-                parked = 0u;
-                start_sample(slot[0], slot[blockDim.x], mk(slot[2u * blockDim.x], slot[3u * blockDim.x], slot[4u * blockDim.x]), (uint32_t)*kslot);
-            }
-        } else if (phase == PH_GEN) {
-            float dx, dy;
-            V3 dir;
-            uint32_t k_after;
-            gen_ray(s, dx, dy, dir, k_after);
-            start_sample(dx, dy, dir, k_after);
-        }
-        // every new segment of this round -- primary rays, scattered rays, resumed paths -- is set up here, once
-        PF_MARK(1);
-        ISA_MARK("begin");
-        PB(3, phase == PH_BEGIN);
-        if (phase == PH_BEGIN) {
-            begin_segment(t.o, t.d);
-            phase = (ACCEL == RTMI_ACCEL_BVH && P.root_ref == kNoWalk) ? PH_SHADE : PH_TRAV;
-        }
-
-        // waves in the traversal loop issue ahead of waves that shade, draw or fetch: the loop is where the lanes are
-        // (A/B on MI355X: +1.3 %; the other way round -0.4 %)
-        ISA_MARK("walk");
-        __builtin_amdgcn_s_setprio(RTMI_WALK_PRIO);
-        PF_MARK(2);
-        // ---- TRAVERSE ---------------------------------------------------------------------------------------------
-        if (ACCEL == RTMI_ACCEL_BVH) {
-            // Two kinds of step: an internal node (two slab tests) or a leaf (its spheres).  Each iteration the wave
-            // runs only the kind that holds more of its traversing lanes; the other lanes keep their place.
-            // leave when wait_thresh lanes wait for shading; the stragglers keep their state and go on next round
-            // (A/B on MI355X: counting finished lanes as waiting too was 0-5 % slower).  Inside the loop lanes only move
-            // from TRAV to SHADE, so the test is on the number still traversing: no third vote, no reload per trip.
-            // A lane walks iff its t.cur is a node or a leaf reference: a finished walk leaves the sentinel there (and lanes
-            // that never walked start with it), so the two votes come straight from t.cur -- no phase compare, no mask
-            // algebra in the loop (every instruction of this loop, scalar ones included, is paid ~15 times per round:
-            // ten more s_add per trip cost the frame 4.3 %, ten more v_mov 2.8 %, measured).
-            const int trav_floor = max(0, (int)__popcll(ballot(phase == PH_TRAV || phase == PH_SHADE)) - (int)P.wait_thresh);
-            for (;;) {
-#if RTMI_ASM_WALK && !(defined(RTMI_PROF) && RTMI_PROF == 1)
-                if (!STATS && (!BIG || RTMI_WPE_BIG <= 6)) {
-                    int n_leaf, n_node;
-                    if (BIG) walk_nodes_hbm(t, lds_nodes, lds0, P.lds_top_nodes, sp_stride, trav_floor, n_leaf, n_node);
-                    else walk_nodes_lds(t, lds0, sp_stride, trav_floor, n_leaf, n_node); // nodes start the dynamic LDS segment
-                    if (n_leaf + n_node <= trav_floor) break;
-                    if ((int32_t)t.cur < -1) { // the leaf step won the vote
-                        test_leaf(t.cur);
-                        t.sp -= sp_stride;
-                        t.cur = (uint32_t)(int32_t)*stack_at(t.sp);
-                    }
-                    continue;
-                }
-#endif
-                const bool at_leaf = (int32_t)t.cur < -1, at_node = (int32_t)t.cur >= 0; // (inline constants)
-                const uint64_t m_leaf = ballot(at_leaf);
-                const uint64_t m_node = ballot(at_node);
-#if defined(RTMI_PROF) && RTMI_PROF == 1
-                // pfl: 0 leaf trips, 1 lanes stepping in them, 2 lanes parked at a node meanwhile; 3 node trips, 4 lanes stepping, 5 parked at a leaf
-                if (__popcll(m_leaf) > __popcll(m_node)) { PF_COUNT(0); PF_LANES(1, m_leaf); PF_LANES(2, m_node); } else if (__popcll(m_leaf) + __popcll(m_node) > trav_floor) { PF_COUNT(3); PF_LANES(4, m_node); PF_LANES(5, m_leaf); }
-#endif
-                int n_leaf = (int)__popcll(m_leaf), n_node = (int)__popcll(m_node);
-                // keep the counts 32-bit scalars: left alone the compiler compares the 64-bit popcounts, for which
-                // the scalar unit has no greater-than, and moves the vote's outcome through the vector unit
-                asm volatile("" : "+s"(n_leaf), "+s"(n_node));
-                if (n_leaf + n_node <= trav_floor) break; // also: nobody walks
-                // (one merged pop behind both branches: writing it out in each of them was measured 3 % slower)
-                bool pop = false;
-                if (n_leaf > n_node) {
-                    PF_MARK(3);
-                    if (at_leaf) {
-                        test_leaf(t.cur);
-                        pop = true;
-                    }
-                    PF_MARK(21);
-                } else if (at_node) {
-                    NodeFields nd;
-                    if (BIG) { // 48-byte records: the staged top of the tree from LDS, the rest through L1 / L2 / Infinity Cache (config 4)
-                        uint4 n0, n1, n2;
-                        if (t.cur < P.lds_top_nodes) {
-                            typedef __attribute__((address_space(3))) uint32_t lds_u32;
-                            const lds_u32* np = (const lds_u32*)(uintptr_t)(lds0 + 48u * t.cur);
-                            n0 = make_uint4(np[0], np[1], np[2], np[3]);
-                            n1 = make_uint4(np[4], np[5], np[6], np[7]);
-                            n2 = make_uint4(np[8], np[9], np[10], np[11]);
-                        } else {
-                            const uint4* np = lds_nodes + 3u * t.cur;
-                            n0 = np[0]; n1 = np[1]; n2 = np[2];
-                        }
-                        nd = unpack_node48(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z);
-                    } else { // the same records in LDS
-                        const uint4* np = lds_nodes + 3u * t.cur;
-                        const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
-                        nd = unpack_node48(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z);
-                    }
-                    const float c0x = nd.c0x, c0y = nd.c0y, c0z = nd.c0z, c1x = nd.c1x, c1y = nd.c1y, c1z = nd.c1z;
-                    const float h0x = nd.h0x, h0y = nd.h0y, h0z = nd.h0z, h1x = nd.h1x, h1y = nd.h1y, h1z = nd.h1z;
-                    const float ax = __builtin_fabsf(t.inv.x), ay = __builtin_fabsf(t.inv.y), az = __builtin_fabsf(t.inv.z);
-                    // slab test in centre/half form: the pad rides in the FMA of the half extent
-                    const float tc0x = __builtin_fmaf(c0x, t.inv.x, t.oinv.x), th0x = __builtin_fmaf(h0x, ax, t.pinv.x);
-                    const float tc0y = __builtin_fmaf(c0y, t.inv.y, t.oinv.y), th0y = __builtin_fmaf(h0y, ay, t.pinv.y);
-                    const float tc0z = __builtin_fmaf(c0z, t.inv.z, t.oinv.z), th0z = __builtin_fmaf(h0z, az, t.pinv.z);
-                    const float tc1x = __builtin_fmaf(c1x, t.inv.x, t.oinv.x), th1x = __builtin_fmaf(h1x, ax, t.pinv.x);
-                    const float tc1y = __builtin_fmaf(c1y, t.inv.y, t.oinv.y), th1y = __builtin_fmaf(h1y, ay, t.pinv.y);
-                    const float tc1z = __builtin_fmaf(c1z, t.inv.z, t.oinv.z), th1z = __builtin_fmaf(h1z, az, t.pinv.z);
-                    // fmaxf/fminf drop a NaN operand (0 * inf on an axis-parallel ray), which keeps the test conservative
-                    const float tn0 = fmaxf(fmaxf(tc0x - th0x, tc0y - th0y), fmaxf(tc0z - th0z, 0.0001f));
-                    // (the far limit goes in through one hand-placed v_min_f32 per box: fminf on a value the compiler cannot
-                    // prove quiet costs a canonicalising v_max_f32 per trip; tbest is +inf or a finite root)
-                    float zf0 = tc0z + th0z, zf1 = tc1z + th1z;
-                    asm("v_min_f32 %0, %1, %2" : "=v"(zf0) : "v"(zf0), "v"(t.tbest));
-                    asm("v_min_f32 %0, %1, %2" : "=v"(zf1) : "v"(zf1), "v"(t.tbest));
-                    const float tf0 = fminf(fminf(tc0x + th0x, tc0y + th0y), zf0);
-                    const float tn1 = fmaxf(fmaxf(tc1x - th1x, tc1y - th1y), fmaxf(tc1z - th1z, 0.0001f));
-                    const float tf1 = fminf(fminf(tc1x + th1x, tc1y + th1y), zf1);
-                    if (STATS) st_node += 2;
-                    const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
-                    const uint32_t ch0 = nd.ch0, ch1 = nd.ch1;
-                    asm volatile("" ::"v"(ch0), "v"(ch1)); // keep the child-reference read with the box reads (one LDS round trip)
-                    // flat on purpose: selects instead of nested branches (each nesting level is an exec-mask
-                    // save / restore and a branch of the wave)
-                    const bool nearer1 = tn1 < tn0;
-                    const bool take1 = hit1 & (!hit0 | nearer1); // nearer child first (bitwise: no short-circuit branches)
-                    // the far child is written above the stack top unconditionally (the stack has one spare level) and only
-                    // counts when both boxes are hit: no exec-mask save / restore around the push
-                    *stack_at(t.sp) = (StackS)(take1 ? ch0 : ch1);
-                    t.sp += (hit0 & hit1) ? sp_stride : 0u;
-                    t.cur = take1 ? ch1 : ch0; // overwritten by the pop when neither box is hit
-                    pop = !(hit0 | hit1);
-                }
-                if (pop) {
-                    t.sp -= sp_stride;
-                    t.cur = (uint32_t)(int32_t)*stack_at(t.sp);
-                }
-            }
-            if (phase == PH_TRAV && t.cur == kStackEnd) phase = PH_SHADE; // popped the sentinel: the walk is over
-        } else {
-            // the reference's linear closest-hit scan (object.defs.cc:68-81); all lanes of a wave read the same
-            // sphere, so every LDS read is a broadcast.
-            if (ballot(phase == PH_TRAV) != 0ull) {
-                if (phase == PH_TRAV) {
-                    uint32_t i = 0;
-                    const Recip ra = recip_for(t.a); // shared by every root of this segment
-                    for (; i + 4u <= P.n_slots; i += 4u) { // four broadcast reads in flight, four discriminants, then the rare roots
-                        const uint4 r0 = lds_spheres[i], r1 = lds_spheres[i + 1u], r2 = lds_spheres[i + 2u], r3 = lds_spheres[i + 3u];
-                        float h0, h1, h2, h3, d0, d1, d2, d3;
-                        sphere_delta(r0, t, h0, d0);
-                        sphere_delta(r1, t, h1, d1);
-                        sphere_delta(r2, t, h2, d2);
-                        sphere_delta(r3, t, h3, d3);
-                        if (fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) { // insertion order, as the reference scans
-                            if (d0 >= 0.0f) sphere_root(h0, d0, t, ra, i, t.tbest, t.best);
-                            if (d1 >= 0.0f) sphere_root(h1, d1, t, ra, i + 1u, t.tbest, t.best);
-                            if (d2 >= 0.0f) sphere_root(h2, d2, t, ra, i + 2u, t.tbest, t.best);
-                            if (d3 >= 0.0f) sphere_root(h3, d3, t, ra, i + 3u, t.tbest, t.best);
-                        }
-                    }
-                    for (; i < P.n_slots; ++i) {
-                        float h0, d0;
-                        sphere_delta(lds_spheres[i], t, h0, d0);
-                        if (d0 >= 0.0f) sphere_root(h0, d0, t, ra, i, t.tbest, t.best);
-                    }
-                    if (STATS) st_sphere += P.n_slots;
-                    phase = PH_SHADE;
-                }
-            }
-        }
-
-        PF_MARK(3);
-        PF_LANES(6, ballot(phase == PH_DONE));
-        // ---- SHADE: compute_color's hit/miss handling (core.cc:242-256) and Material::scatter ------------------
-        // unit vectors for every Lambertian / Metallic hit of this round, generated by the whole wave together
-        ISA_MARK("request");
-        __builtin_amdgcn_s_setprio(0);
-        uint32_t rq = RQ_NONE; // Lambertian / Metallic hit: a unit vector; Dielectric hit: one draw
-        if (phase == PH_SHADE && t.best < kBlackSample) rq = lds_aux[t.best].w != 2u ? RQ_UNIT : RQ_WORD;
-        PF_MARK(4);
-        ISA_MARK("draws");
-        rng.sample = s; // (defined where it is used: not a register across the walk)
-        const V3 unit_vec = coop_draws(rq, rng, P.seed, rank_tbl PB_PASS);
-        ISA_MARK("shade");
-        PF_MARK(7);
-        PB(8, phase == PH_SHADE);
-        PB(9, phase == PH_SHADE && t.best < kBlackSample);
-        PB(14, phase == PH_SHADE && t.best == ~0u);
-        PB(15, phase == PH_SHADE && t.best == ~0u && (natt != 0u || run_n != 0u));
-#if defined(RTMI_PROF) && RTMI_PROF == 2
-        { // (census votes are taken outside the divergent code they describe: inside it the compiler may move them)
-            const uint32_t kind_c = (phase == PH_SHADE && t.best < kBlackSample) ? lds_aux[t.best].w : 3u;
-            PB(10, kind_c == 0u);
-            PB(11, kind_c == 1u);
-            PB(12, kind_c == 2u);
-        }
-#endif
-        PB(22, rq == RQ_WORD || (phase == PH_SHADE && t.best == ~0u)); // the shared normalize(ray.direction)
-        if (phase == PH_SHADE) {
-            bool ended = false;
-            V3 color = mk(0.0f, 0.0f, 0.0f);
-            // unit_vector(ray.direction) of the Dielectric scatter (material.defs.cc:60) and of the sky gradient
-            // (core.cc:254): one evaluation for the lanes of both branches instead of one per branch (-1.6 %; folding the
-            // Metallic branch's normalize(reflect(d, N)) into it as well gained nothing more)
-            V3 unit_dir = mk(0.0f, 0.0f, 0.0f);
-            if (rq == RQ_WORD || t.best == ~0u) unit_dir = vnormalize(t.d);
-            if (t.best == kBlackSample) {
-                ended = true; // maxdepth == 0: black sample
-            } else if (t.best != ~0u) {
-                ISA_MARK("shade-hit-record");
-                PF_MARK(8);
-                // IntersectionRecord for the winning sphere, object.defs.cc:62-65 and :11-18
-                const uint4 sraw = lds_spheres[t.best];
-                const uint4 araw = lds_aux[t.best];
-                const V3 C = mk(__uint_as_float(sraw.x), __uint_as_float(sraw.y), __uint_as_float(sraw.z));
-                const float R = __uint_as_float(araw.z);
-                const V3 p = vadd(t.o, vscale(t.d, t.tbest)); // Ray::point_at_param, ray.hpp:9
-                const V3 pc = vsub(p, C);
-                const V3 outward = vdivs_shared(pc, R, comps_in_range(pc)); // (p - C) / R, object.defs.cc:13
-                const bool front = vdot(t.d, outward) < 0.0f;
-                const V3 N = front ? outward : vneg(outward);
-                const uint32_t mh = araw.y;
-                const uint4 m0 = lds_mats[mh]; // {albedo, fuzz} or {refraction index, ...}
-                ISA_MARK("shade-material");
-                PF_MARK(9);
-                const uint32_t kind = araw.w;
-                V3 sd = mk(0.0f, 0.0f, 0.0f);
-                bool scattered = true;
-                if (kind != 2u) {
-                    // Lambertian (material.defs.cc:31-42) and Metallic (:44-55) share ONE rejection loop for their
-                    // random_unit_vector(): the wave pays the longest run of rejections once, not once per material.
-                    V3 rn = mk(0.0f, 0.0f, 0.0f);
-                    if (kind == 1u) rn = vnormalize(vreflect(t.d, N));
-                    const V3 u = unit_vec; // random_unit_vector(), random.number.gen.hpp:21-29
-                    if (kind == 0u) {
-                        sd = vadd(N, u);
-                        const float eps = 1e-8f; // near_zero, ray.tracer.math.hpp:16-19
-                        if (__builtin_fabsf(sd.x) < eps && __builtin_fabsf(sd.y) < eps && __builtin_fabsf(sd.z) < eps) sd = N;
-                    } else {
-                        sd = vadd(rn, vscale(u, __uint_as_float(m0.w)));
-                        scattered = vdot(sd, N) > 0.0f;
-                    }
-                    PF_MARK(10);
-                } else { // Material_Dielectric::scatter, material.defs.cc:57-87
-                    ISA_MARK("shade-dielectric");
-                    // eta = front ? 1/ri : ri and r1 = ((1 - eta) / (1 + eta))^2 (material.defs.cc:58, 80-82) depend on the
-                    // material and the face only: both pairs are computed once on the host with the same fp32 operations
-                    const float eta = front ? __uint_as_float(m0.y) : __uint_as_float(m0.x);
-                    const float r1 = front ? __uint_as_float(m0.z) : __uint_as_float(m0.w);
-                    const float cos_theta = fminf(vdot(vneg(unit_dir), N), 1.0f);
-                    const float sin_theta = sqrt_shared(1.0f - cos_theta * cos_theta);
-                    bool reflect_it = (eta * sin_theta) > 1.0f;
-                    PB(13, !reflect_it);
-                    if (!reflect_it) { // short-circuit ||: the draw happens only when refraction is possible
-                        // powf(x, 5): x^5 through double is the correctly rounded value except for ties
-                        const double xd = (double)(1.0f - cos_theta);
-                        const double x2 = xd * xd;
-                        const float p5 = (float)((x2 * x2) * xd);
-                        const float schlick = r1 + (1.0f - r1) * p5;
-                        const double u = (double)__float_as_uint(unit_vec.x) * 2.3283064365386963e-10; // the draw at rng.k
-                        rng.k++;
-                        reflect_it = (double)schlick > u;
-                    }
-                    sd = reflect_it ? vreflect(unit_dir, N) : vrefract(unit_dir, N, eta);
-                    PF_MARK(11);
-                }
-                ISA_MARK("shade-continue");
-                if (!scattered) {
-                    ended = true; // absorbed: compute_color returns 0 (core.cc:251)
-                } else {
-                    if (kind != 2u) att_push(mh); // dielectric attenuation is (1,1,1): multiplying by it is exact, skip
-                    depth_left--;
-                    if (depth_left == 0) {
-                        ended = true; // the next compute_color call returns 0 (core.cc:238-240)
-                    } else {
-                        t.o = p;
-                        t.d = sd;
-                        phase = PH_BEGIN; // set up before the next traversal, together with the new primary rays
-                    }
-                }
-                PF_MARK(12);
-            } else {
-                ISA_MARK("shade-miss");
-                PF_MARK(8);
-                // miss: sky gradient (core.cc:254-256), then the attenuations innermost-first (core.cc:247-248)
-                const float tt = 0.5f * (unit_dir.y + 1.0f);
-                color = vadd(vscale(mk(1.0f, 1.0f, 1.0f), 1.0f - tt), vscale(mk(0.5f, 0.7f, 1.0f), tt));
-                ISA_MARK("shade-replay");
-                PF_MARK(13);
-                if (PACKED) {
-                    // the string leaves with the sample: whole 16-byte groups of words (the slot is a multiple of four
-                    // words; rows past the last written one are never read back)
-                    if (natt != 0u) {
-                        uint32_t nw = run_n >> 8;
-                        if ((run_n & 255u) != 0u) lds_att[nw++ * blockDim.x + threadIdx.x] = run_h;
-                        uint4* dst = reinterpret_cast<uint4*>(P.chain_buf + ((size_t)lpix * spp + s) * P.att_words);
-                        for (uint32_t w = 0; w < nw; w += 4u) {
-                            const uint32_t* row = lds_att + w * blockDim.x + threadIdx.x;
-                            dst[w >> 2] = make_uint4(row[0], row[blockDim.x], row[2u * blockDim.x], row[3u * blockDim.x]);
-                        }
-                    }
-                } else {
-                color = att_apply(color, run_h, run_n);
-                if (!BIG) {
-                    const uint32_t full = natt >> 2; // whole windows that went to HBM; the rest is still in LDS
-                    for (uint32_t q = natt; q > 4u * full;) {
-                        --q;
-                        const uint32_t e = lds_att[(q & 3u) * blockDim.x + threadIdx.x];
-                        color = att_apply(color, e & 0xffffu, e >> 16);
-                    }
-                    // (the strip is read back one block ahead of the multiplies: the next block's load is in flight while
-                    // the four runs of this one are applied)
-                    const uint4* strip = reinterpret_cast<const uint4*>(P.att_stack) + (size_t)glane * att_blocks;
-                    uint4 blk = full != 0u ? strip[full - 1u] : make_uint4(0u, 0u, 0u, 0u);
-                    for (uint32_t b = full; b-- > 0u;) {
-                        const uint4 cur_blk = blk;
-                        if (b != 0u) blk = strip[b - 1u];
-                        color = att_apply(color, cur_blk.w & 0xffffu, cur_blk.w >> 16);
-                        color = att_apply(color, cur_blk.z & 0xffffu, cur_blk.z >> 16);
-                        color = att_apply(color, cur_blk.y & 0xffffu, cur_blk.y >> 16);
-                        color = att_apply(color, cur_blk.x & 0xffffu, cur_blk.x >> 16);
-                    }
-                } else {
-                    for (uint32_t q = natt; q-- > 0u;) {
-                        const uint32_t h = P.att_stack[((size_t)glane * maxdepth + q) * 2u];
-                        const uint32_t n = P.att_stack[((size_t)glane * maxdepth + q) * 2u + 1u];
-                        color = att_apply(color, h, n);
-                    }
-                }
-                }
-                ended = true;
-                PF_MARK(14);
-            }
-            ISA_MARK("shade-ended");
-            PB(16, ended);
-            PB(17, ended && t.best != ~0u);
-            if (ended) {
-                // raytrace_pixel, core.cc:259-265: sequential sum, then scale and pack
-                if (!WHOLE) {
-                    // one 16-byte record per sample, stored as soon as the sample is finished.  (Round 1 kept an even sample in
-                    // three registers until its odd partner could leave with it as one 32-byte sector: half the write-backs at
-                    // the fabric, but the path is not bound by HBM and the registers are worth more.)
-                    // (.w: 0, or in MODE 4 the length of the chain the resolve pass still has to multiply into the sky colour)
-                    const uint32_t pending = (PACKED && t.best == ~0u) ? natt : 0u;
-                    P.sample_buf[(size_t)lpix * spp + s] = make_float4(color.x, color.y, color.z, __uint_as_float(pending));
-                } else {
-                    sum = vadd(sum, color);
-                }
-                s++;
-                if (STATS) st_samples++;
-                if (STATS && P.tile_cost != nullptr && s >= s_end) { // probe launch: what this work item cost, into its tile of the whole image
-                    const uint32_t gy_c = fdiv(rng.pixel, P.div_w), px_c = rng.pixel - gy_c * W;
-                    atomicAdd(&P.tile_cost[(gy_c >> 3) * P.gtiles_x + (px_c >> 3)], st_segments - st_item0);
-                    st_item0 = st_segments;
-                }
-                if (s >= s_end && !WHOLE) {
-                    phase = PH_FETCH; // chunk done; rtmi_resolve_kernel finishes the pixel
-                } else if (s >= s_end) {
-                    const V3 outc = vscale(sum, P.cam.pixels_sample_scale);
-                    const size_t o = lpix;
-                    if (P.out_rgb) {
-                        P.out_rgb[3 * o + 0] = outc.x;
-                        P.out_rgb[3 * o + 1] = outc.y;
-                        P.out_rgb[3 * o + 2] = outc.z;
-                    }
-                    if (P.out_rgba) {
-                        // RGBAColor(vec3), color.hpp:30-36
-                        auto ch = [](float v) -> uint32_t {
-                            const float g = v > 0.0f ? __builtin_sqrtf(v) : 0.0f;
-                            const float c = g < 0.0f ? 0.0f : (g > 0.999f ? 0.999f : g);
-                            return (uint32_t)(uint8_t)(c * 256.0f);
-                        };
-                        P.out_rgba[o] = ch(outc.x) | (ch(outc.y) << 8) | (ch(outc.z) << 16) | (255u << 24);
-                    }
-                    phase = PH_FETCH;
-                } else {
-                    phase = PH_GEN;
-                }
-                PF_MARK(15);
-            }
-        }
-        ISA_MARK("loop-end");
-    }
-
-#ifdef RTMI_TAILPROBE
-    if (lane == 0 && P.tail_probe) P.tail_probe[3u * tp_wave + 2u] = wall_clock64();
-#endif
-#if defined(RTMI_PROF) && RTMI_PROF == 1
-    PF_MARK(16);
-    if (lane == 0) {
-        for (int q = 0; q < PF_SLOTS; ++q) atomicAdd(&P.stats[8 + q], (unsigned long long)pft[q]);
-        for (int q = 0; q < 12; ++q) atomicAdd(&P.stats[32 + q], (unsigned long long)pfl[q]);
-    }
-#elif defined(RTMI_PROF)
-    if (lane == 0) {
-        for (int q = 0; q < PB_SLOTS; ++q) {
-            atomicAdd(&P.stats[64 + 2 * q], (unsigned long long)pb_n[q]);
-            atomicAdd(&P.stats[65 + 2 * q], (unsigned long long)pb_l[q]);
-        }
-    }
-#endif
-    if (STATS) {
-        atomicAdd(&P.stats[0], (unsigned long long)st_samples);
-        atomicAdd(&P.stats[1], (unsigned long long)st_segments);
-        atomicAdd(&P.stats[2], (unsigned long long)st_sphere);
-        atomicAdd(&P.stats[3], (unsigned long long)st_node);
-    }
-}
-
-#undef glane
-#undef lane
-
-// Ordered resolve of the sample-chunk split: pixel_color += sample, s = 0 .. spp-1, exactly the sequential fp32 sum of
-// raytrace_pixel (core.cc:260-263), then * pixels_sample_scale and RGBAColor (core.cc:264, color.hpp:30-36).
-// One lane per pixel, 128 bytes per lane and trip: HBM-bound (5.7 TB/s at 1080p x 512 spp).
-struct ResolveArgs;
-DEV void resolve_store(const ResolveArgs& A, uint32_t p, V3 sum);
-struct ResolveArgs {
-    const float4* sample_buf;
-    const uint32_t* chain_buf;
-    const uint4* mats;
-    uint32_t n_mats, bits, epw, words;
-    FastDiv div_epw;
-    uint32_t n_pixels, spp;
-    float scale;
-    float* out_rgb;
-    uint32_t* out_rgba;
-};
-DEV void resolve_store(const ResolveArgs& A, uint32_t p, V3 sum) {
-    const V3 outc = vscale(sum, A.scale);
-    if (A.out_rgb) {
-        A.out_rgb[3u * p + 0u] = outc.x;
-        A.out_rgb[3u * p + 1u] = outc.y;
-        A.out_rgb[3u * p + 2u] = outc.z;
-    }
-    if (A.out_rgba) {
-        auto ch = [](float v) -> uint32_t {
-            const float g = v > 0.0f ? __builtin_sqrtf(v) : 0.0f;
-            const float c = g < 0.0f ? 0.0f : (g > 0.999f ? 0.999f : g);
-            return (uint32_t)(uint8_t)(c * 256.0f);
-        };
-        A.out_rgba[p] = ch(outc.x) | (ch(outc.y) << 8) | (ch(outc.z) << 16) | (255u << 24);
-    }
-}
-
-// (round 5, rocprofv3 kernel stats on the 1080p x 512 spp frame: 4 records a trip in blocks of 256 lanes 3.285 ms, 8 a trip -- a whole 128-byte
-// line per lane -- 3.090, 8 a trip in blocks of 64 lanes 2.998 ms = 5.7 TB/s; 4 a trip in blocks of 64: 3.331)
-#define RTMI_RESOLVE_BLOCK 64
-__global__ void __launch_bounds__(RTMI_RESOLVE_BLOCK) rtmi_resolve_kernel(const ResolveArgs A) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.n_pixels) return;
-    const uint32_t spp = A.spp;
-    const float4* src = A.sample_buf + (size_t)p * spp;
-    V3 sum = mk(0.0f, 0.0f, 0.0f);
-    uint32_t k = 0;
-    for (; k + 8u <= spp; k += 8u) { // a whole 128-byte line per lane and trip
-        const float4 c0 = src[k], c1 = src[k + 1u], c2 = src[k + 2u], c3 = src[k + 3u];
-        const float4 c4 = src[k + 4u], c5 = src[k + 5u], c6 = src[k + 6u], c7 = src[k + 7u];
-        sum = vadd(sum, mk(c0.x, c0.y, c0.z));
-        sum = vadd(sum, mk(c1.x, c1.y, c1.z));
-        sum = vadd(sum, mk(c2.x, c2.y, c2.z));
-        sum = vadd(sum, mk(c3.x, c3.y, c3.z));
-        sum = vadd(sum, mk(c4.x, c4.y, c4.z));
-        sum = vadd(sum, mk(c5.x, c5.y, c5.z));
-        sum = vadd(sum, mk(c6.x, c6.y, c6.z));
-        sum = vadd(sum, mk(c7.x, c7.y, c7.z));
-    }
-    for (; k + 4u <= spp; k += 4u) { // a whole 64-byte line per lane and trip
-        const float4 c0 = src[k], c1 = src[k + 1u], c2 = src[k + 2u], c3 = src[k + 3u];
-        sum = vadd(sum, mk(c0.x, c0.y, c0.z));
-        sum = vadd(sum, mk(c1.x, c1.y, c1.z));
-        sum = vadd(sum, mk(c2.x, c2.y, c2.z));
-        sum = vadd(sum, mk(c3.x, c3.y, c3.z));
-    }
-    for (; k < spp; ++k) {
-        const float4 c = src[k];
-        sum = vadd(sum, mk(c.x, c.y, c.z));
-    }
-    resolve_store(A, p, sum);
-}
-
-// The resolve pass of MODE 4 launches: a record whose .w is nonzero holds the sky colour of a path and the length of its
-// attenuation chain; the chain (material handles, first bounce first, `bits` wide, `epw` per word, in chain_buf next to
-// the record) is multiplied in innermost-first, which is compute_color's A1 * (A2 * (... * sky)) (core.cc:247-248) bit
-// for bit.  A wave takes kResPix pixels at a time: for each of them its lanes load 64 consecutive samples (records and
-// chain slots are contiguous across the lanes: coalesced, where one lane per pixel would touch 64 B per sample in 64
-// different lines) and multiply their chains in parallel -- a chain is serial, the samples are not; the colours go to an
-// LDS tile and lanes 0 .. kResPix-1 add their pixel's 64 colours up in sample order (core.cc:260-263).  Albedos in LDS.
-constexpr uint32_t kResPix = 4, kResRow = 65; // (65: the summing lanes read one column, a power-of-two row stride would put them in one bank)
-__global__ void __launch_bounds__(256) rtmi_resolve_chain_kernel(const ResolveArgs A) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    uint4* lds_mats = reinterpret_cast<uint4*>(lds_raw);
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
-    float4* tile = reinterpret_cast<float4*>(lds_raw + (((size_t)A.n_mats * sizeof(uint4) + 15u) & ~(size_t)15u)) + (size_t)wave * kResPix * kResRow;
-    for (uint32_t i = threadIdx.x; i < A.n_mats; i += blockDim.x) lds_mats[i] = A.mats[i];
-    __syncthreads();
-    const uint32_t spp = A.spp, mask = (1u << A.bits) - 1u; // (bits <= 16)
-    const uint32_t n_groups = (A.n_pixels + kResPix - 1u) / kResPix;
-    for (uint32_t g = blockIdx.x * n_waves + wave; g < n_groups; g += gridDim.x * n_waves) {
-        const uint32_t p0 = g * kResPix, np = min(kResPix, A.n_pixels - p0);
-        V3 sum = mk(0.0f, 0.0f, 0.0f); // lanes < np: the running sum of pixel p0 + lane
-        for (uint32_t b = 0; b < spp; b += 64u) {
-            const uint32_t cnt = min(64u, spp - b);
-            for (uint32_t q = 0; q < np; ++q) {
-                if (lane < cnt) {
-                    const size_t rec = (size_t)(p0 + q) * spp + b + lane;
-                    const float4 c = A.sample_buf[rec];
-                    V3 color = mk(c.x, c.y, c.z);
-                    const uint32_t n = __float_as_uint(c.w);
-                    if (n != 0u) {
-                        // word by word from the last handle back to the first; within a word four handles at a time: their
-                        // albedo reads are in flight together (a chain is one LDS round trip per handle otherwise: the
-                        // multiplies depend on the read, the read on the handle)
-                        const uint4* ch = reinterpret_cast<const uint4*>(A.chain_buf + rec * A.words);
-                        uint32_t wi = fdiv(n - 1u, A.div_epw);
-                        uint32_t c = n - wi * A.epw; // handles in the last word
-                        uint4 grp = ch[wi >> 2];
-                        auto pick = [&](uint32_t w) { const uint32_t s_ = w & 3u; return s_ == 0u ? grp.x : (s_ == 1u ? grp.y : (s_ == 2u ? grp.z : grp.w)); };
-                        auto albedo = [&](uint32_t h) { const uint4 m0 = lds_mats[h]; return mk(__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z)); };
-                        const uint32_t bits = A.bits;
-                        for (;;) {
-                            const uint32_t word = pick(wi);
-                            uint32_t sh = c * bits; // one past the top handle of this word
-                            for (; c >= 4u; c -= 4u, sh -= 4u * bits) {
-                                const V3 a0 = albedo((word >> (sh - bits)) & mask), a1 = albedo((word >> (sh - 2u * bits)) & mask);
-                                const V3 a2 = albedo((word >> (sh - 3u * bits)) & mask), a3 = albedo((word >> (sh - 4u * bits)) & mask);
-                                color = vmul(a0, color);
-                                color = vmul(a1, color);
-                                color = vmul(a2, color);
-                                color = vmul(a3, color);
-                            }
-                            for (; c != 0u; --c, sh -= bits) color = vmul(albedo((word >> (sh - bits)) & mask), color);
-                            if (wi == 0u) break;
-                            if ((wi & 3u) == 0u) grp = ch[(wi - 1u) >> 2];
-                            --wi;
-                            c = A.epw;
-                        }
-                    }
-                    tile[q * kResRow + lane] = make_float4(color.x, color.y, color.z, 0.0f);
-                }
-            }
-            // the tile passes colours between the lanes of ONE wave: the hardware keeps a wave's LDS accesses in order, the
-            // language's memory model needs to be told -- a wavefront-scope release / acquire pair around a wave barrier (no
-            // instruction on gfx950 beyond the waitcnt the reads need anyway) keeps the compiler from moving the row reads above
-            // the tile writes, or the next block's writes above these reads
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < np) {
-                const float4* row = tile + lane * kResRow;
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    const float4 c = row[i];
-                    sum = vadd(sum, mk(c.x, c.y, c.z));
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        if (lane < np) resolve_store(A, p0 + lane, sum);
-    }
-}
+#include "rtmi_trace_kernel.h"
+#include "rtmi_resolve.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // host side of the C-ABI
@@ -2448,3 +1244,4 @@ extern "C" int rtmi_prof_read(rtmi_scene* s, unsigned long long* out128) {
     return hipMemcpy(out128, s->d_stats, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 #endif
+

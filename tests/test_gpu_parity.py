@@ -815,10 +815,10 @@ def test_render_rect_tiles_the_frame(pkg, ob, rtow, gpu):
                 assert err.value.code == pkg.RTMI_ERR_BAD_ARG
 
 
-def test_cost_ordered_tiles_and_overlapped_bands_do_not_change_the_image(pkg, ob, rtow, gpu):
-    """Round 5 scheduling: the 8x8 tiles of a launch handed out costliest first (per-tile segment counts from one probe launch
-    per scene), and a call rendered in bands of rows that alternate between two streams of the library so that a band's
-    ordered resolve pass and tail run beside the next band's trace kernel.  Neither changes a bit: whole frames, row ranges that
+def test_cost_ordered_tiles_and_sequential_bands_do_not_change_the_image(pkg, ob, rtow, gpu):
+    """Scheduling: the 8x8 tiles of a launch handed out costliest first (per-tile segment counts from one probe launch per
+    scene), and a call rendered in bands of rows (rtmi_tuning::bands), one launch sequence after the other on the caller's
+    stream.  Neither changes a bit: whole frames, row ranges that
     do not start on a tile row, sharded row blocks, rectangles, both accel paths, packed and run-length chains; the launch
     report says what the most recent call did; back-to-back asynchronous calls on one stream stay ordered."""
     torch = gpu
@@ -855,7 +855,7 @@ def test_cost_ordered_tiles_and_overlapped_bands_do_not_change_the_image(pkg, ob
                 torch.cuda.synchronize()
                 frame = torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev)).cpu().numpy()
                 _assert_frames_equal(frame, want)
-    # the box of config 5 (packed chains multiplied by the resolve pass) in overlapped bands
+    # the box of config 5 (packed chains multiplied by the resolve pass) in six sequential bands
     g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
     ccam = pkg.camera_setup(pkg.camera_params(**json.loads(str(g["camera"]))))
     with pkg.Scene(ccam, g["objects"], g["materials"], tuning=dict(tile_order=2, bands=6)) as s:
@@ -872,7 +872,7 @@ def test_differential_fuzz_slice(pkg, ob, gpu):
     """A slice of tools/fuzz_vs_oracle.py where the driver runs it (the round-4 log of 9 800 worlds is
     profiles/r04_fuzz_vs_oracle.txt): 200 random worlds -- 1-90 spheres, every fourth 100-600 spheres over a field hundreds of
     radii wide; negative radii, scales 1e-2 .. 1e3, bounce limits up to 120 -- through the walk x {LDS, HBM with the top of the
-    tree staged / not staged, either pad rule, run-length chains, whole-pixel items, cost-ordered tiles in overlapped bands}
+    tree staged / not staged, either pad rule, run-length chains, whole-pixel items, cost-ordered tiles in three sequential bands}
     and the scan x 4 variants, every float against the oracle (NaN = NaN)."""
     rng = np.random.default_rng(505)
     bad = []
