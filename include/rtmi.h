@@ -135,8 +135,17 @@ typedef struct rtmi_tuning {
                                  * 2 = costliest first always */
     uint32_t bands;             /* a call whose sample records pass the cap (sample_buf_mb) is rendered in bands of rows, one after
                                  * the other: 0 / 1 = as many bands as the cap asks for (one if the call fits), n > 1 = at least n */
-    uint32_t gen_ahead;         /* packed-chain scenes: primary rays generated ahead into per-lane LDS slots (whenever some lane must
-                                 * generate one, the others generate their next sample's): 0 = where the slots fit, 1 = off */
+    uint32_t gen_ahead;         /* ignored since 0.6 (0.5: primary rays of packed-chain scenes generated ahead into per-lane LDS slots; the
+                                 * same-box A/B of round 6 showed its code cost the config-5 frame 3 % whether switched on or off) */
+    /* ---- added in 0.6 ---- */
+    uint32_t cam_entry;         /* camera rays start their walk at the entry of their 8x8 tile -- the lowest common ancestor of every
+                                 * sphere the tile's beam (lens disk x tile rectangle on the focus plane) can meet, nowhere when it meets
+                                 * none -- instead of the root: 0 = for trees staged into LDS (measured: -3.2 % on the 1080p S-RTOW frame,
+                                 * +2.7 % on the HBM-resident 100k-sphere tree, whose top levels are the cheap ones), 1 = off, 2 = always */
+    uint32_t walk_start;        /* where the walks of scattered rays start: 0 = default, 1 = always at the root */
+    uint32_t stack_cap;         /* HBM-resident trees: entries of a lane's traversal stack kept in LDS (the rest of a deeper walk spills
+                                 * to memory): 0 = default, n > 0 = n */
+    uint32_t reserved6;
 } rtmi_tuning;
 
 typedef struct rtmi_scene_options {
@@ -216,7 +225,12 @@ int rtmi_render_rect_device(rtmi_scene* scene, uint32_t x0, uint32_t y0, uint32_
  * slice of n_blocks*block_rows rows.  Outputs are DEVICE pointers (either may be NULL); the launch is
  * asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).  Launches on one scene share its work
  * counter and sample buffers: issue them on ONE stream (or wait for the previous one) -- use one scene per stream
- * for concurrent frames. */
+ * for concurrent frames.
+ * What "asynchronous" covers (0.6): the scene's cost probe is made by rtmi_scene_create, so no call probes.  A call only
+ * enqueues work on `hip_stream` once the scene has seen its geometry; the FIRST call with a new geometry (another set of rows or
+ * columns), or one that needs larger record buffers than the scene holds, also allocates device memory on the host side
+ * (hipMalloc, and hipFree -- which waits for the device -- when a buffer grows) and uploads a 4-byte-per-tile order table in
+ * front of its kernel: such a call can block for the device and cannot be stream-captured; repeat it once before capturing. */
 int rtmi_render_row_blocks_device(rtmi_scene* scene, uint32_t y_first, uint32_t block_rows, uint32_t block_stride,
                                   uint32_t n_blocks, uint64_t seed, void* d_rgb_linear_out, void* d_rgba8_out,
                                   void* hip_stream);
@@ -252,7 +266,14 @@ typedef struct rtmi_launch_info {
     uint32_t bands;         /* bands of rows it was rendered in (0: no call yet) */
     uint32_t tile_order;    /* 1: its tiles were handed out costliest first, 0: row by row */
     uint32_t probe_us;      /* duration of the scene's cost probe launch in microseconds (0: none was made) */
-    uint32_t gen_ahead;     /* 1: primary rays are generated ahead into LDS slots (rtmi_tuning::gen_ahead) */
+    uint32_t gen_ahead;     /* always 0 since 0.6 (see rtmi_tuning::gen_ahead) */
+    /* ---- added in 0.6 ---- */
+    uint32_t cam_entry;     /* 1: camera rays start at their tile's entry (rtmi_tuning::cam_entry) */
+    uint32_t entry_build_us;/* host time rtmi_scene_create spent on the table of entries, microseconds */
+    uint32_t walk_start;    /* what rtmi_tuning::walk_start resolved to (0: every scattered ray's walk starts at the root) */
+    uint32_t stack_cap;     /* stack entries per lane kept in LDS when the stack is capped (0: the whole stack is in LDS) */
+    uint32_t reband_retries;/* times a call was planned again for half the record cap because the device refused a band's buffers
+                             * (memory held by other scenes, the caller or another process): more, smaller bands, the same image */
 } rtmi_launch_info;
 int rtmi_scene_get_launch_info(const rtmi_scene* scene, rtmi_launch_info* out);
 /* BVH export: call with NULL buffers to get the counts. pad_classes: n_classes x 8 floats {lo[3], hi[3], 1/(2*rmin), rmax^2}. */
@@ -268,6 +289,15 @@ int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf
 int rtmi_bvh_build_passes(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, uint32_t bvh_passes,
                           rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref,
                           uint32_t* depth, float* pad_classes_out, uint32_t* n_classes, float* pad_eps, float* pad_floor);
+/* The scene's table of camera-ray entries (0.6; rtmi_tuning::cam_entry), in the format of rtmi_tile_entries_build below; *n_tiles = 0 when
+ * the scene has none (camera rays walk from the root).  entries_out may be NULL (count only). */
+int rtmi_scene_get_tile_entries(const rtmi_scene* scene, uint32_t* entries_out, uint32_t* n_tiles);
+/* Host-only (0.6): the table of camera-ray entries rtmi_scene_create builds for this camera and these objects (rtmi_tuning::cam_entry) --
+ * per 8x8 tile of the image, row-major over ceil(W / 8) x ceil(H / 8) tiles, the reference (rtmi_bvh_node::child format, of the tree
+ * rtmi_bvh_build_passes returns for the same arguments) of the lowest common ancestor of the leaves of every sphere a sample of the
+ * tile can hit, 0xffffffff when it can hit none.  entries_out may be NULL (count only). */
+int rtmi_tile_entries_build(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size,
+                            uint32_t bvh_passes, uint32_t* entries_out, uint32_t* n_tiles);
 /* Milliseconds the TRACE kernels of the most recent call on this scene took (the bands of a banded call added up; the
  * ordered resolve passes between them are not included), from HIP events recorded on the launch stream; blocks until that
  * call has finished.  Used by bench.py for the roofline line. */

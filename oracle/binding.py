@@ -135,6 +135,24 @@ def set_pad_mode(mode):
     lib().orc_set_pad_mode(int(mode))
 
 
+_tile_entries = None  # (kept alive while the oracle points at it)
+
+
+def set_tile_entries(entries):
+    """Camera-ray entries of the instrumented BVH walk: the (tiles_y, tiles_x) uint32 table of the product's
+    rtmi_tile_entries_build, or None = every walk from the root."""
+    global _tile_entries
+    L = lib()
+    L.orc_set_tile_entries.argtypes = [C.c_void_p, C.c_uint32]
+    L.orc_set_tile_entries.restype = None
+    if entries is None:
+        L.orc_set_tile_entries(None, 0)
+        _tile_entries = None
+    else:
+        _tile_entries = np.ascontiguousarray(entries, dtype=np.uint32)
+        L.orc_set_tile_entries(_tile_entries.ctypes.data_as(C.c_void_p), _tile_entries.shape[1])
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -229,12 +247,14 @@ def render_rect_counter(cam, objs, mats, seed, x0, y0, x1, y1, nthreads=1, count
     else:
         nodes = np.ascontiguousarray(bvh["nodes"])
         slots = np.ascontiguousarray(bvh["slots"], dtype=np.uint32)
+        set_tile_entries(bvh.get("entries"))  # (the camera-ray entries of the scene the tree came from, if it has any)
         pc = np.ascontiguousarray(bvh["pad_classes"], dtype=np.float32).reshape(-1, 8)
         assert nodes.dtype.itemsize == 64
         rc = lib().orc_render_rect_counter_bvh(C.byref(cam), _ptr(objs), len(objs), _ptr(mats), len(mats),
                                                _ptr(nodes), len(nodes), _ptr(slots), len(slots), _ptr(pc), len(pc),
                                                bvh["pad_eps"], bvh["pad_floor"], seed, x0, y0, x1, y1, _ptr(rgb),
                                                _ptr(rgba), cp, nthreads)
+        set_tile_entries(None)
     assert rc == 0, rc
     return (rgb, rgba, ctr.as_dict()) if counters else (rgb, rgba)
 

@@ -601,6 +601,15 @@ static inline float ray_pad(const scene_t* sc, const ray_t* r, const float inv[3
 
 /* instrumentation of the walk (counters only, never the image): the object the current segment starts on, ~0u for a camera ray */
 static __thread uint32_t g_origin_obj = 0xffffffffu;
+/* Camera-ray entries (build-side, round 6; the product's rtmi_tuning::cam_entry): per 8x8 tile of the image the reference of the
+ * node or leaf the walks of that tile's camera rays start at (the product's host code proves that no sample of the tile can hit
+ * a sphere outside it: csrc/rtmi_host.cpp, build_tile_entries), 0xffffffff = no walk at all.  The oracle only FOLLOWS the table,
+ * so that its test counters price what the kernel does and a CPU test can hold the table against the linear scan. */
+#define ORC_FROM_ROOT 0xfffffffeu
+static const uint32_t* g_tile_entries = NULL;
+static uint32_t g_tile_entries_gtx = 0;
+static __thread uint32_t g_entry_ref = ORC_FROM_ROOT;
+void orc_set_tile_entries(const uint32_t* entries, uint32_t gtx) { g_tile_entries = entries; g_tile_entries_gtx = gtx; }
 static int path_to_slot(const scene_t* sc, uint32_t ref, uint32_t slot, uint32_t* path, int depth) {
     if (ref & 0x80000000u) {
         const uint32_t first = ref & 0x00ffffffu, count = (ref >> 24) & 0x7fu;
@@ -663,6 +672,9 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
                 best = oi;
             }
         }
+    }
+    if (g_entry_ref != ORC_FROM_ROOT && !no_walk) { /* a camera ray of a tile with an entry: start there (or nowhere) */
+        if (g_entry_ref == 0xffffffffu) no_walk = 1; else cur = g_entry_ref;
     }
     /* the pad of this segment's boxes, with the far limit the peeled leaves left */
     const float pad = ray_pad(sc, r, inv, oinv, best_t);
@@ -862,6 +874,7 @@ static v3 compute_color(const ray_t* r, uint32_t depth, const scene_t* sc, orc_r
     const int hit = sc->nodes || sc->n_slots ? bvh_intersects(sc, r, 0.0001f, &rec, &hit_index, ctr)
                                              : world_intersects(sc, r, 0.0001, (double)INFINITY, &rec, NULL, ctr);
     g_origin_obj = hit ? hit_index : 0xffffffffu; /* (counters of the instrumented walk: where the next segment starts) */
+    g_entry_ref = ORC_FROM_ROOT;                  /* (every scattered ray walks from the root) */
     if (hit) {
         const orc_material* m = &sc->mats[rec.material]; /* MaterialCollection::operator[], material.defs.hpp:102 */
         v3 att;
@@ -889,6 +902,7 @@ static void raytrace_pixel(const orc_camera* cam, const scene_t* sc, uint32_t x,
         }
         const ray_t r = get_ray(cam, x, y, rng);
         g_origin_obj = 0xffffffffu; /* (walk counters: a camera ray) */
+        g_entry_ref = g_tile_entries ? g_tile_entries[(y >> 3) * g_tile_entries_gtx + (x >> 3)] : ORC_FROM_ROOT;
         pixel_color = vadd(pixel_color, compute_color(&r, cam->maxdepth, sc, rng, ctr));
         if (ctr) ctr->samples++;
     }

@@ -129,6 +129,9 @@ int orc_get_counter_rng(void);
  * the segment (the product's, round 4), 2 = none (not exact: lower bound of the walk's work, measurements only) */
 void orc_set_pad_mode(int mode);
 int orc_get_pad_mode(void);
+/* camera-ray entries of the instrumented BVH walk (the product's rtmi_tile_entries_build table, rtmi_bvh_node::child format,
+ * row-major over gtx tiles per row; NULL = every walk from the root).  The table must outlive the renders that use it. */
+void orc_set_tile_entries(const uint32_t* entries, uint32_t gtx);
 void orc_counter_block(uint32_t blk, uint32_t sample, uint32_t pixel, const uint32_t key[2], uint32_t out[4]);
 
 /* --- host-side setup ------------------------------------------------------ */

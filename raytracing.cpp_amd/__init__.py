@@ -82,7 +82,8 @@ class Tuning(C.Structure):  # rtmi_tuning: scheduling knobs, 0 = default; none o
                 ("chain_mode", C.c_int32), ("bvh_passes", C.c_uint32), ("sample_buf_mb", C.c_uint32),
                 ("force_hbm_scene", C.c_uint32), ("top_down", C.c_uint32), ("kernel", C.c_uint32),
                 ("reserved3", C.c_uint32 * 3), ("lds_top_nodes", C.c_uint32), ("tile_order", C.c_uint32),
-                ("bands", C.c_uint32), ("gen_ahead", C.c_uint32)]
+                ("bands", C.c_uint32), ("gen_ahead", C.c_uint32),
+                ("cam_entry", C.c_uint32), ("walk_start", C.c_uint32), ("stack_cap", C.c_uint32), ("reserved6", C.c_uint32)]
 
 
 class SceneOptions(C.Structure):
@@ -94,7 +95,8 @@ class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("struct_size", "kernel", "block_lanes", "grid_blocks", "blocks_per_cu",
                                           "lds_bytes", "scene_in_lds", "stack_depth", "whole_pixel_fallbacks",
                                           "packed_chains", "packed_chain_fallbacks", "lds_top_nodes", "pad_mode",
-                                          "bands", "tile_order", "probe_us", "gen_ahead")]
+                                          "bands", "tile_order", "probe_us", "gen_ahead",
+                                          "cam_entry", "entry_build_us", "walk_start", "stack_cap", "reband_retries")]
 
 
 class FrameTiming(C.Structure):
@@ -105,7 +107,7 @@ def make_tuning(**kw):
     """rtmi_tuning from keyword arguments (field names of include/rtmi.h); unknown names are an error."""
     t = Tuning()
     t.struct_size = C.sizeof(Tuning)
-    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved3"}
+    names = {n for n, _ in Tuning._fields_} - {"struct_size", "reserved3", "reserved6"}
     for k, v in kw.items():
         if k not in names:
             raise KeyError(f"unknown tuning knob {k!r}")
@@ -140,7 +142,7 @@ EXPORTS = ("rtmi_camera_setup", "rtmi_make_world_spheres", "rtmi_scene_create", 
            "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_render_rect", "rtmi_render_rect_device",
            "rtmi_last_error", "rtmi_version",
            "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_launch_info", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
-           "rtmi_bvh_build", "rtmi_bvh_build_passes", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
+           "rtmi_bvh_build", "rtmi_bvh_build_passes", "rtmi_tile_entries_build", "rtmi_scene_get_tile_entries", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
            "rtmi_frame_render_device", "rtmi_frame_get_timing", "rtmi_frame_rccl_ranks", "rtmi_frame_get_scene")
 
 _lib = None
@@ -187,6 +189,9 @@ def lib():
     L.rtmi_bvh_build.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u32p, vp, u32p, u32p, vp, u32p, f32p, f32p]
     if hasattr(L, "rtmi_bvh_build_passes"):  # (absent from older builds that tools/ A/B against the current one)
         L.rtmi_bvh_build_passes.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p, vp, u32p, u32p, vp, u32p, f32p, f32p]
+    if hasattr(L, "rtmi_tile_entries_build"):  # (absent from older builds that tools/ A/B against the current one)
+        L.rtmi_tile_entries_build.argtypes = [C.POINTER(Camera), vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p]
+        L.rtmi_scene_get_tile_entries.argtypes = [vp, vp, u32p]
     L.rtmi_frame_create.argtypes = [C.POINTER(Camera), vp, C.c_uint32, vp, C.c_uint32, C.POINTER(SceneOptions),
                                     C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.rtmi_frame_destroy.argtypes = [vp]
@@ -360,7 +365,15 @@ class Scene:
         slots = np.zeros(ns.value, np.uint32)
         pc = np.zeros((nc.value, 8), np.float32)
         _check(lib().rtmi_scene_get_bvh(self._h, _ptr(nodes), None, _ptr(slots), None, _ptr(pc), None, None, None))
-        return dict(nodes=nodes, slots=slots, pad_classes=pc, pad_eps=eps.value, pad_floor=floor.value)
+        entries = None  # camera-ray entries per 8x8 tile (rtmi_tuning::cam_entry), for an instrumented CPU walk that follows them
+        if hasattr(lib(), "rtmi_scene_get_tile_entries"):
+            nt = C.c_uint32(0)
+            _check(lib().rtmi_scene_get_tile_entries(self._h, None, C.byref(nt)))
+            if nt.value:
+                entries = np.zeros(((self.height + 7) // 8, (self.width + 7) // 8), np.uint32)
+                assert entries.size == nt.value
+                _check(lib().rtmi_scene_get_tile_entries(self._h, _ptr(entries), C.byref(nt)))
+        return dict(nodes=nodes, slots=slots, pad_classes=pc, pad_eps=eps.value, pad_floor=floor.value, entries=entries)
 
 
 class Frame:
@@ -432,6 +445,18 @@ def bvh_build(objs, leaf_size=0, bvh_passes=0):
                                        C.byref(root), C.byref(depth), _ptr(pc), C.byref(nc), C.byref(eps), C.byref(floor)))
     return dict(nodes=nodes[:nn.value].copy(), slots=slots[:n].copy(), pad_classes=pc[:nc.value].copy(),
                 pad_eps=eps.value, pad_floor=floor.value, root_ref=root.value, depth=depth.value)
+
+
+def tile_entries_build(cam, objs, leaf_size=0, bvh_passes=0):
+    """rtmi_tile_entries_build: the camera-ray entry of every 8x8 tile of the image (no device needed), shape (tiles_y, tiles_x);
+    references into the tree bvh_build returns for the same arguments, 0xffffffff = the tile's beam meets no sphere of the tree."""
+    objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
+    gtx, gty = (cam.img_width + 7) // 8, (cam.img_height + 7) // 8
+    out = np.zeros((gty, gtx), np.uint32)
+    n = C.c_uint32(0)
+    _check(lib().rtmi_tile_entries_build(C.byref(cam), _ptr(objs), len(objs), leaf_size, bvh_passes, _ptr(out), C.byref(n)))
+    assert n.value == gtx * gty
+    return out
 
 
 def row_block_shards(height, block_rows, world_size):

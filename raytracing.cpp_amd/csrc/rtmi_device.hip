@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -129,6 +130,9 @@ struct rtmi_scene {
     uint4* d_aux = nullptr;
     uint4* d_mats = nullptr;
     uint4* d_nodes = nullptr;
+    uint32_t* d_tile_entry = nullptr; // camera-ray entry per 8x8 tile of the image (build_tile_entries), NULL: walks start at the root
+    std::vector<uint32_t> tile_entries; // the same table in the builder's reference format (rtmi_scene_get_tile_entries: the tests' instrumented CPU walk)
+    float entry_build_ms = 0.0f;
     unsigned long long* d_stats = nullptr;
     unsigned long long* d_tail = nullptr; // -DRTMI_TAILPROBE builds only
     float* d_rgb = nullptr;     // staging for rtmi_render_rows / rtmi_render_rect (host-pointer entries)
@@ -147,6 +151,7 @@ struct rtmi_scene {
     bool ev_valid = false;
     uint32_t whole_pixel_fallbacks = 0; // launches that could not get their sample-record buffer
     uint32_t packed_chain_fallbacks = 0; // launches of a packed-chain scene that ran with run-length encoded chains
+    uint32_t reband_retries = 0;         // times a call's plan was made again for half the cap because the device refused a band's buffers
     bool top_down = false;
     bool pad_refine = false; // box pad bounded by the segment's reach (rtmi_tuning::pad_mode; default: where it pays, Bvh::pad_refine)
     // cost-ordered hand-out of the 8x8 tiles (rtmi_tuning::tile_order): segments per tile of the whole image from one probe
@@ -160,6 +165,7 @@ struct rtmi_scene {
     struct OrderEntry {
         uint32_t key[6]; // y_first, block_rows, block_stride, n_blocks, x0, x1
         uint32_t* d_order;
+        std::vector<uint32_t> h_order; // (kept: the upload is asynchronous on the stream of the call that made the entry)
         uint32_t n_tiles;
         double cost;     // sum over the entry's tiles
     };
@@ -173,7 +179,6 @@ struct rtmi_scene {
     uint32_t wait_thresh = 52;
 
     uint32_t lds_att = 0, lds_pool = 0;
-    uint32_t lds_ahead = 0;     // packed-chain scenes with room for them: per-lane slots of primary rays generated ahead (GEN phase)
     uint32_t lds_top_nodes = 0; // HBM-resident trees: breadth-first nodes staged into LDS (48-byte records at the start of the segment)
     uint32_t n_cus = 0;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
@@ -212,6 +217,7 @@ void free_scene(rtmi_scene* s) {
     hipFree(s->d_aux);
     hipFree(s->d_mats);
     hipFree(s->d_nodes);
+    hipFree(s->d_tile_entry);
     hipFree(s->d_stats);
     hipFree(s->d_tail);
     hipFree(s->d_rgb);
@@ -241,6 +247,7 @@ void fill_scene_params(const rtmi_scene* s, RtmiLaunch& P) {
     P.root_ref = s->root_ref_dev;
     std::memcpy(P.pre_leaf, s->pre_leaf_dev, sizeof(P.pre_leaf));
     P.n_pre_leaves = s->n_pre_leaves;
+    P.tile_entry = s->d_tile_entry;
     std::memcpy(P.pad_classes, s->bvh.pad_classes, sizeof(P.pad_classes));
     P.n_pad_classes = s->bvh.n_pad_classes;
     P.pad_eps = s->bvh.pad_eps;
@@ -255,7 +262,6 @@ void fill_scene_params(const rtmi_scene* s, RtmiLaunch& P) {
     P.lds_top_nodes = s->lds_top_nodes;
     P.lds_att = s->lds_att;
     P.lds_pool = s->lds_pool;
-    P.lds_ahead = s->lds_ahead;
     P.stack_depth = s->stack_depth;
     P.top_down = s->top_down ? 1u : 0u;
     P.wait_thresh = s->wait_thresh;
@@ -289,14 +295,15 @@ int count_rows(const rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint3
 }
 
 // The probe behind the cost-ordered hand-out: the whole image at 2 samples per pixel through the counting variant of the kernel
-// (whole-pixel work items, no outputs), every work item adding its segment count to its 8x8 tile.  Once per scene, on the
-// caller's stream, blocking; a failure only switches the ordering off.
+// (whole-pixel work items, no outputs), every work item adding its segment count to its 8x8 tile.  Once per scene, made by
+// rtmi_scene_create on the scene's own stream (round 6: the render entries are asynchronous from the first call on; rounds 5 made
+// it inside the first large call, on the caller's stream, blocking); a failure only switches the ordering off.
 void probe_tile_costs(rtmi_scene* s, hipStream_t stream) {
     s->cost_state = -1;
     const uint32_t W = s->cam.img_width, H = s->cam.img_height;
     const uint32_t gtx = (W + 7u) / 8u, gty = (H + 7u) / 8u;
     const size_t n = (size_t)gtx * gty;
-    if (n == 0 || n > 0x7fffffffu) return;
+    if (n == 0 || n * 64u > 0xffffffffull - (1ull << 24)) return; // (the bound of launch_one: room for the refills past the end)
     uint32_t* d_cost = nullptr;
     unsigned long long* d_pstats = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -382,14 +389,16 @@ const rtmi_scene::OrderEntry* order_for(rtmi_scene* s, uint32_t y_first, uint32_
         }
     }
     std::sort(keyed.begin(), keyed.end(), std::greater<uint64_t>());
-    std::vector<uint32_t> order(n);
-    for (size_t i = 0; i < n; ++i) order[i] = 0xffffffffu - (uint32_t)keyed[i];
     auto e = std::make_unique<rtmi_scene::OrderEntry>();
+    e->h_order.resize(n);
+    for (size_t i = 0; i < n; ++i) e->h_order[i] = 0xffffffffu - (uint32_t)keyed[i];
     std::memcpy(e->key, key, sizeof(key));
     e->n_tiles = (uint32_t)n;
     e->cost = total;
+    e->d_order = nullptr;
+    // (stream-ordered in front of the kernel that reads it; the host copy lives as long as the entry)
     if (hipMalloc(reinterpret_cast<void**>(&e->d_order), std::max<size_t>(n, 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMemcpy(e->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpyAsync(e->d_order, e->h_order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream) != hipSuccess) {
         hipFree(e->d_order);
         (void)hipGetLastError();
         return nullptr;
@@ -402,9 +411,8 @@ const rtmi_scene::OrderEntry* order_for(rtmi_scene* s, uint32_t y_first, uint32_
 // band's trace kernel sits between its own pair of events)
 int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks,
                uint32_t x0, uint32_t x1, uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream, uint32_t band,
-               const rtmi_scene::OrderEntry* order) {
+               const rtmi_scene::OrderEntry* order, size_t per_slot_cap) {
     LaunchSlot& sl = s->slot[0];
-    const size_t per_slot_cap = s->sample_buf_cap_bytes;
     const uint32_t W = s->cam.img_width;
     uint32_t n_local_rows = 0;
     const int rc_rows = count_rows(s, y_first, block_rows, block_stride, n_blocks, n_local_rows);
@@ -459,6 +467,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
             chunk = std::min(chunk, by_cost);
         }
     }
+    if (chunk && spp > chunk && sample_floats * sizeof(float4) > per_slot_cap) s->whole_pixel_fallbacks++; // (not even one unit of rows fits what the device has left)
     if (chunk && spp > chunk && sample_floats * sizeof(float4) <= per_slot_cap) {
         if (sample_floats > sl.samples_capacity) {
             hipFree(sl.d_samples);
@@ -585,39 +594,87 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     // a band is a run of units: 8 rows of a contiguous call (tile rows stay whole), or one row block of a sharded call
     const bool contiguous = n_blocks == 1;
     const uint32_t rows_c = contiguous ? std::min(block_rows, H - y_first) : 0u;
-    const uint64_t row_bytes = (uint64_t)Wl * spp * (sizeof(float4) + (s->packed_ok ? (size_t)s->att_words * 4u : 0u));
-    const uint64_t max_rows = row_bytes ? s->sample_buf_cap_bytes / row_bytes : 0;
-    const bool split_on = s->chunk != 0u && spp > 4u && max_rows >= 1;
-    uint32_t unit_rows = contiguous ? (max_rows >= 8 ? 8u : 1u) : block_rows;
-    uint32_t n_units = contiguous ? (rows_c + unit_rows - 1u) / unit_rows : n_blocks;
-    uint32_t n_bands = 1;
-    if (split_on && unit_rows <= max_rows) {
-        const uint64_t units_per_band = std::max<uint64_t>(1u, max_rows / unit_rows);
-        n_bands = (uint32_t)((n_units + units_per_band - 1) / units_per_band);
-        n_bands = std::min(n_units, std::max(n_bands, s->min_bands)); // (rtmi_tuning::bands asks for more than memory does: tests, experiments)
-    }
-    const uint32_t per_band = (n_units + n_bands - 1u) / n_bands;
-    n_bands = (n_units + per_band - 1u) / per_band;
-
+    const uint64_t sample_bytes = sizeof(float4) + (s->packed_ok ? (size_t)s->att_words * 4u : 0u);
+    const uint64_t row_bytes = (uint64_t)Wl * spp * sample_bytes;
     struct Band {
         uint32_t y_first, block_rows, n_blocks; // (block_stride: the call's)
         size_t row0;                            // first row of the band in the call's dense output
         uint32_t rows;
         const rtmi_scene::OrderEntry* order;
     };
-    std::vector<Band> bands(n_bands);
-    for (uint32_t k = 0; k < n_bands; ++k) {
-        const uint32_t u0 = k * per_band, nu = std::min(per_band, n_units - u0);
-        Band& b = bands[k];
-        if (contiguous) {
-            const uint32_t r0 = u0 * unit_rows, nr = std::min(nu * unit_rows, rows_c - r0);
-            b = Band{y_first + r0, nr, 1u, (size_t)r0, nr, nullptr};
+    std::vector<Band> bands;
+    uint32_t n_bands = 1;
+    // The cap on one band's records (+ chain slots): rtmi_tuning::sample_buf_mb or a third of the device's memory, and never more than
+    // the device has left beside what this scene's slot already holds (other scenes' retained buffers, the caller's own allocations,
+    // another process): round 5's unrecorded abort was a tree that sized three such buffers from the device's TOTAL
+    // memory.  The largest band's buffers are allocated here, before anything is launched; if the device refuses them the plan is
+    // made again for half the cap -- more, smaller bands, the same image -- and only a cap below one unit of rows falls back to
+    // whole-pixel work items / run-length chains (launch_one; counted in rtmi_launch_info).
+    LaunchSlot& sl = s->slot[0];
+    size_t cap = s->sample_buf_cap_bytes;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t held = sl.samples_capacity * sizeof(float4) + sl.chain_capacity * (size_t)s->att_words * 4u;
+            const size_t reserve = std::max<size_t>((size_t)512 << 20, total_b / 64u);
+            const size_t avail = free_b + held;
+            cap = std::min(cap, avail > reserve ? avail - reserve : (size_t)0);
         } else {
-            uint32_t rows = 0;
-            const int rc = count_rows(s, y_first + u0 * block_stride * block_rows, block_rows, block_stride, nu, rows);
-            if (rc != RTMI_OK) return rc;
-            b = Band{y_first + u0 * block_stride * block_rows, block_rows, nu, (size_t)u0 * block_rows, rows, nullptr};
+            (void)hipGetLastError();
         }
+    }
+    for (int attempt = 0;; ++attempt) {
+        const uint64_t max_rows = row_bytes ? cap / row_bytes : 0;
+        const bool split_on = s->chunk != 0u && spp > 4u && max_rows >= 1;
+        const uint32_t unit_rows = contiguous ? (max_rows >= 8 ? 8u : 1u) : block_rows;
+        const uint32_t n_units = contiguous ? (rows_c + unit_rows - 1u) / unit_rows : n_blocks;
+        n_bands = 1;
+        if (split_on && unit_rows <= max_rows) {
+            const uint64_t units_per_band = std::max<uint64_t>(1u, max_rows / unit_rows);
+            n_bands = (uint32_t)((n_units + units_per_band - 1) / units_per_band);
+            n_bands = std::min(n_units, std::max(n_bands, s->min_bands)); // (rtmi_tuning::bands asks for more than memory does: tests, experiments)
+        }
+        const uint32_t per_band = (n_units + n_bands - 1u) / n_bands;
+        n_bands = (n_units + per_band - 1u) / per_band;
+        bands.assign(n_bands, Band{});
+        uint32_t max_band_rows = 0;
+        for (uint32_t k = 0; k < n_bands; ++k) {
+            const uint32_t u0 = k * per_band, nu = std::min(per_band, n_units - u0);
+            Band& b = bands[k];
+            if (contiguous) {
+                const uint32_t r0 = u0 * unit_rows, nr = std::min(nu * unit_rows, rows_c - r0);
+                b = Band{y_first + r0, nr, 1u, (size_t)r0, nr, nullptr};
+            } else {
+                uint32_t rows = 0;
+                const int rc = count_rows(s, y_first + u0 * block_stride * block_rows, block_rows, block_stride, nu, rows);
+                if (rc != RTMI_OK) return rc;
+                b = Band{y_first + u0 * block_stride * block_rows, block_rows, nu, (size_t)u0 * block_rows, rows, nullptr};
+            }
+            max_band_rows = std::max(max_band_rows, b.rows);
+        }
+        // the buffers of the largest band, now (a band that fits the cap only; launch_one decides the rest exactly as before)
+        const size_t need = (size_t)max_band_rows * Wl * spp;
+        const bool wants_records = split_on && need * sizeof(float4) <= cap;
+        if (!wants_records) break;
+        bool ok = true;
+        if (need > sl.samples_capacity) {
+            hipFree(sl.d_samples); // (hipFree waits for the device: an earlier asynchronous call may still be reading the old buffer)
+            sl.d_samples = nullptr;
+            sl.samples_capacity = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&sl.d_samples), need * sizeof(float4)) == hipSuccess) sl.samples_capacity = need;
+            else { (void)hipGetLastError(); ok = false; }
+        }
+        if (ok && s->packed_ok && need * sample_bytes <= cap && need > sl.chain_capacity) {
+            hipFree(sl.d_chain);
+            sl.d_chain = nullptr;
+            sl.chain_capacity = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&sl.d_chain), need * (size_t)s->att_words * 4u) == hipSuccess) sl.chain_capacity = need;
+            else { (void)hipGetLastError(); ok = false; }
+        }
+        if (ok) break;
+        if (attempt >= 12 || cap / 2u < row_bytes) break; // (launch_one falls back and counts it)
+        cap /= 2u;
+        s->reband_retries++;
     }
     // cost-ordered tiles: where a launch has tiles to order and samples enough for the probe to be small next to it, and the
     // scene is in LDS -- a tree read through the caches wants neighbouring tiles in flight together (config 4, 100k spheres, 64 spp:
@@ -626,7 +683,6 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     const bool want_order = s->tile_order_mode == 2u || (s->tile_order_mode == 0u && !s->big && tiles_total >= 2048u && spp >= 16u);
     s->last_tile_order = 0;
     if (want_order && n_bands <= 256u) {
-        if (s->cost_state == 0) probe_tile_costs(s, stream);
         if (s->orders.size() + n_bands > 512u) { // (a host that walks through many geometries: start over rather than grow)
             HIP_TRY(hipDeviceSynchronize());
             for (auto& e : s->orders) hipFree(e->d_order);
@@ -642,7 +698,7 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     auto out_rgba = [&](const Band& b) { return d_rgba ? d_rgba + b.row0 * Wl : nullptr; };
     for (uint32_t k = 0; k < n_bands; ++k) {
         const Band& b = bands[k];
-        const int rc = launch_one(s, b.y_first, b.block_rows, block_stride, b.n_blocks, x0, x1, seed, out_rgb(b), out_rgba(b), stream, k, b.order);
+        const int rc = launch_one(s, b.y_first, b.block_rows, block_stride, b.n_blocks, x0, x1, seed, out_rgb(b), out_rgba(b), stream, k, b.order, cap);
         if (rc != RTMI_OK) return rc;
         s->n_bands_timed = k + 1u;
     }
@@ -832,12 +888,6 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     }
     s->lds_pool = off; // per wave: {work_next, work_end, slot_next, slot_end}
     off += (s->block / 64u) * 80u; // + 64-byte rank table of coop_draws
-    // packed-chain scenes whose two workgroups per CU still fit with 21 bytes a lane more: slots for primary rays generated ahead
-    if (s->packed_ok && tune.gen_ahead != 1u && align16(off) + 21u * s->block + 16u <= 80u * 1024u) {
-        off = align16(off);
-        s->lds_ahead = off;
-        off += 21u * s->block;
-    }
     s->lds_bytes = align16(off);
     if (s->lds_bytes > 160u * 1024u) {
         set_error("rtmi_scene_create: traversal stack does not fit the 160 KiB LDS of a CU (BVH too deep)");
@@ -862,6 +912,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
             return (ref & kLeafBit) ? (0xffff8000u | ((((ref >> 24) & 0x7fu) - 1u) << 13) | (ref & 0x1fffu)) : ref;
         };
         s->root_ref_dev = s->bvh.root_ref;
+        uint32_t walk_root = s->bvh.root_ref;
         if (!s->big && s->accel == RTMI_ACCEL_BVH && n_objects > 0) {
             for (auto& nd : dn) {
                 nd.child[0] = pack16(nd.child[0]);
@@ -871,23 +922,12 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         }
         // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start
         // every walk below them
+        auto dev_ref = [&](uint32_t ref) { return ref == kNoWalkRef ? kNoWalk : (s->big ? ref : pack16(ref)); };
         if (s->accel == RTMI_ACCEL_BVH && !dn.empty()) {
-            uint32_t cur = s->bvh.root_ref;
-            while (!(cur & kLeafBit) && s->n_pre_leaves < 4u) {
-                const rtmi_bvh_node& nd = s->bvh.nodes[cur];
-                const bool l0 = (nd.child[0] & kLeafBit) != 0u, l1 = (nd.child[1] & kLeafBit) != 0u;
-                if (l0 && l1 && s->n_pre_leaves + 2u <= 4u) { // the spine ends in two leaves: nothing left to walk
-                    s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? nd.child[0] : pack16(nd.child[0]);
-                    s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? nd.child[1] : pack16(nd.child[1]);
-                    cur = kNoWalk;
-                    break;
-                }
-                if (l0 == l1) break;
-                const uint32_t leaf = l0 ? nd.child[0] : nd.child[1];
-                s->pre_leaf_dev[s->n_pre_leaves++] = s->big ? leaf : pack16(leaf);
-                cur = l0 ? nd.child[1] : nd.child[0];
-            }
-            if (s->n_pre_leaves) s->root_ref_dev = (cur == kNoWalk) ? kNoWalk : (s->big ? cur : pack16(cur));
+            uint32_t pre[4];
+            walk_root = peel_top_leaves(s->bvh, pre, s->n_pre_leaves);
+            for (uint32_t q = 0; q < s->n_pre_leaves; ++q) s->pre_leaf_dev[q] = dev_ref(pre[q]);
+            if (s->n_pre_leaves) s->root_ref_dev = dev_ref(walk_root);
         }
         if (!dn.empty()) {
             // 48-byte records: centres fp32, half extents fp16 rounded up (an extent beyond fp16 becomes +inf: always hit),
@@ -928,6 +968,18 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
                 r[10] = dn[i].child[1];
             }
             HIP_TRY_S(upload(&s->d_nodes, rec.data(), rec.size() * sizeof(uint32_t)));
+            // camera rays start at their tile's entry (rtmi_tuning::cam_entry; host: build_tile_entries, csrc/rtmi_host.cpp)
+            if (s->accel == RTMI_ACCEL_BVH && (tune.cam_entry == 2u || (tune.cam_entry == 0u && !s->big)) && walk_root != kNoWalkRef && !(walk_root & kLeafBit)) {
+                const auto t0 = std::chrono::steady_clock::now();
+                std::vector<uint32_t> entries;
+                build_tile_entries(*camera, objects, s->bvh, walk_root, entries);
+                s->tile_entries = entries;
+                for (uint32_t& e : entries) e = dev_ref(e);
+                s->entry_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                uint4* d = nullptr;
+                HIP_TRY_S(upload(&d, entries.data(), entries.size() * sizeof(uint32_t)));
+                s->d_tile_entry = reinterpret_cast<uint32_t*>(d);
+            }
         } else {
             HIP_TRY_S(upload(&s->d_nodes, dn.data(), dn.size() * sizeof(rtmi_bvh_node)));
         }
@@ -1006,6 +1058,12 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->slot[0].d_counter), 16));
     HIP_TRY_S(hipMalloc(reinterpret_cast<void**>(&s->slot[0].d_att), att_bytes));
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    // the cost probe of the tile order, here rather than inside the first call that wants it: no call has more tiles than the frame
+    {
+        const uint64_t frame_tiles = (uint64_t)((camera->img_width + 7u) / 8u) * ((camera->img_height + 7u) / 8u);
+        if (s->tile_order_mode == 2u || (s->tile_order_mode == 0u && !s->big && frame_tiles >= 2048u && camera->samples_per_pixel >= 16u))
+            probe_tile_costs(s, s->stream);
+    }
 #undef HIP_TRY_S
     return RTMI_OK;
 }
@@ -1177,7 +1235,10 @@ extern "C" int rtmi_scene_get_launch_info(const rtmi_scene* s, rtmi_launch_info*
     v.bands = s->last_bands;
     v.tile_order = s->last_tile_order;
     v.probe_us = s->cost_state == 1 ? (uint32_t)(s->probe_ms * 1000.0f + 0.5f) : 0u;
-    v.gen_ahead = s->lds_ahead != 0u ? 1u : 0u;
+    v.gen_ahead = 0u; // (rounds 4-5; removed in round 6)
+    v.cam_entry = s->d_tile_entry != nullptr ? 1u : 0u;
+    v.entry_build_us = (uint32_t)(s->entry_build_ms * 1000.0f + 0.5f);
+    v.reband_retries = s->reband_retries;
     std::memcpy(out, &v, std::min<size_t>(out->struct_size, sizeof(v)));
     return RTMI_OK;
 }
@@ -1201,6 +1262,16 @@ extern "C" int rtmi_scene_get_bvh(const rtmi_scene* s, rtmi_bvh_node* nodes_out,
     if (nodes_out) std::memcpy(nodes_out, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(rtmi_bvh_node));
     if (slots_out) std::memcpy(slots_out, s->bvh.slot_object.data(), s->bvh.slot_object.size() * sizeof(uint32_t));
     if (pad_classes_out) std::memcpy(pad_classes_out, s->bvh.pad_classes, s->bvh.n_pad_classes * 8 * sizeof(float));
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_get_tile_entries(const rtmi_scene* s, uint32_t* entries_out, uint32_t* n_tiles) {
+    if (!s || !n_tiles) {
+        set_error("rtmi_scene_get_tile_entries: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    *n_tiles = (uint32_t)s->tile_entries.size(); // (0: camera rays walk from the root)
+    if (entries_out && !s->tile_entries.empty()) std::memcpy(entries_out, s->tile_entries.data(), s->tile_entries.size() * sizeof(uint32_t));
     return RTMI_OK;
 }
 

@@ -71,7 +71,7 @@ using namespace rtmi;
 
 extern "C" const char* rtmi_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* rtmi_version(void) {
-    return "rtmi 0.5 (gfx950)";
+    return "rtmi 0.6 (gfx950)";
 }
 
 // RayTracingCore::default_setup camera block, reference core.cc:171-216.
@@ -724,6 +724,162 @@ void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, uint3
 
 } // namespace rtmi
 
+// ---------------------------------------------------------------------------------------------------------
+// Leaves peeled off the top of the tree and camera-ray entry points
+// ---------------------------------------------------------------------------------------------------------
+namespace rtmi {
+
+// The top of the tree as a spine of (leaf | subtree) nodes: up to four such leaves (the ground sphere, whose box is the whole
+// scene) are tested at segment set-up and every walk starts below them.  Returns where walks start (a reference in the builder's
+// format) or kNoWalkRef when the peeled leaves were the whole tree.
+uint32_t peel_top_leaves(const Bvh& bvh, uint32_t pre[4], uint32_t& n_pre) {
+    n_pre = 0;
+    uint32_t cur = bvh.root_ref;
+    if (bvh.nodes.empty()) return cur;
+    while (!(cur & kLeafBit) && n_pre < 4u) {
+        const rtmi_bvh_node& nd = bvh.nodes[cur];
+        const bool l0 = (nd.child[0] & kLeafBit) != 0u, l1 = (nd.child[1] & kLeafBit) != 0u;
+        if (l0 && l1 && n_pre + 2u <= 4u) { // the spine ends in two leaves: nothing left to walk
+            pre[n_pre++] = nd.child[0];
+            pre[n_pre++] = nd.child[1];
+            return kNoWalkRef;
+        }
+        if (l0 == l1) break;
+        pre[n_pre++] = l0 ? nd.child[0] : nd.child[1];
+        cur = l0 ? nd.child[1] : nd.child[0];
+    }
+    return cur;
+}
+
+// Camera rays get an entry point (round 6).  Every sample of a pixel of one 8x8 tile is a ray from a point of the lens disk
+// through a point of the tile's rectangle on the focus plane (RayTracingCore::get_ray, core.cc:218-234: origin = cam_center +
+// dx disk_u + dy disk_v with dx^2 + dy^2 < 1, target = pixel00 + (x + ox) du + (y + oy) dv with ox, oy in [-0.5, 0.5)): at ray
+// parameter t its point lies within rho(t) = |1 - t| r_lens + t r_rect of the AXIS point A(t) = cam_center + t (tile centre -
+// cam_center).  A sphere whose root the reference's fp32 arithmetic could accept has the root's point within R + e(L) of its
+// centre, so a sphere the beam never comes within R + e(L) + (rounding of get_ray itself) of can be hit by no
+// sample of the tile, and the tile's walks may start at the LOWEST COMMON ANCESTOR of the leaves of the spheres that remain --
+// or not walk at all when none does (the sky).  The oracle's replay of the kernel's rounds (tools/wave_replay.py) scored it
+// before it was built: camera rays 8.9 -> 2.0 node trips each on S-RTOW, 10.5 -> 9.3 node trips per round of a wave.
+// Exactness does not rest on the order of the walk, only on this list being complete; all of it in double,
+// with the margins below.  entries[tile of the WHOLE image, row-major] = reference in the builder's format, kNoWalkRef = none.
+namespace {
+struct Beam {
+    double a0[3], ax[3], alen, r_lens, r_rect, coord_max;
+    // does the beam come within `reach` of point c (for some t >= 0)?  Two pieces on which rho is linear; on each the squared
+    // distance to the axis minus (reach + rho)^2 is a convex parabola in the arc length s: its minimum over the piece decides.
+    bool reaches(const double c[3], double reach) const {
+        const double w[3] = {c[0] - a0[0], c[1] - a0[1], c[2] - a0[2]};
+        const double h = w[0] * ax[0] + w[1] * ax[1] + w[2] * ax[2];
+        const double q2 = std::max(0.0, w[0] * w[0] + w[1] * w[1] + w[2] * w[2] - h * h);
+        auto piece = [&](double b, double k, double lo, double hi) {
+            const double a = 1.0 - k * k;
+            if (!(a > 1e-6)) return true; // (a beam that opens at 45 degrees or more: no claim)
+            double s = (h + b * k) / a;
+            s = std::min(std::max(s, lo), hi);
+            const double f = q2 + (h - s) * (h - s) - (b + k * s) * (b + k * s);
+            return f <= 1e-9 * (q2 + h * h + b * b);
+        };
+        return piece(reach + r_lens, (r_rect - r_lens) / alen, 0.0, alen) ||
+               piece(reach - r_lens, (r_rect + r_lens) / alen, alen, std::numeric_limits<double>::infinity());
+    }
+    // e(L) of DESIGN.md 5.4 for a sphere of radius r whose centre is at most `l` from any lens point (r = 0: the square-root form),
+    // plus the rounding of get_ray: the fp32 origin and direction are each within ~18u of the ideal ones relative to the largest
+    // coordinate in play, so the fp32 ray's point at parameter t within 64u S (1 + t) of an ideal ray's -- three times over
+    double margin(double l, double r) const {
+        const double u = 5.9604644775390625e-8, x = 64.0 * u * (l * l + r * r);
+        const double e = r > 0.0 ? std::min(x / (2.0 * r), std::sqrt(x)) : std::sqrt(x);
+        const double t_reach = (l + r) / alen + 1.0;
+        return 1.001 * e + 64.0 * u * std::max(coord_max, l + r) * (1.0 + t_reach);
+    }
+};
+} // namespace
+
+void build_tile_entries(const rtmi_camera& cam, const rtmi_object* objects, const Bvh& bvh, uint32_t walk_root,
+                        std::vector<uint32_t>& entries) {
+    const uint32_t gtx = (cam.img_width + 7u) / 8u, gty = (cam.img_height + 7u) / 8u;
+    entries.assign((size_t)gtx * gty, walk_root);
+    if (walk_root == kNoWalkRef || bvh.nodes.empty()) return;
+    double du = 0.0, dv = 0.0, lu = 0.0, lv = 0.0, cmax = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        du += (double)cam.pixel_delta_u[i] * cam.pixel_delta_u[i];
+        dv += (double)cam.pixel_delta_v[i] * cam.pixel_delta_v[i];
+        lu += (double)cam.defocus_disk_u[i] * cam.defocus_disk_u[i];
+        lv += (double)cam.defocus_disk_v[i] * cam.defocus_disk_v[i];
+        const double span = std::fabs((double)cam.pixel_delta_u[i]) * (cam.img_width + 1.0) + std::fabs((double)cam.pixel_delta_v[i]) * (cam.img_height + 1.0);
+        cmax = std::max(cmax, std::fabs((double)cam.pixel00[i]) + span);
+        cmax = std::max(cmax, std::fabs((double)cam.cam_center[i]) + std::fabs((double)cam.defocus_disk_u[i]) + std::fabs((double)cam.defocus_disk_v[i]));
+    }
+    if (!std::isfinite(du + dv + lu + lv + cmax)) return; // (lookfrom == lookat: an all-NaN camera; every walk from the root)
+    Beam b;
+    b.r_rect = 4.0 * (std::sqrt(du) + std::sqrt(dv)) * 1.001; // |a du + b dv|, |a|, |b| <= 4
+    b.r_lens = cam.defocus_angle <= 0.0f ? 0.0 : (std::sqrt(lu) + std::sqrt(lv)) * 1.001;
+    b.coord_max = cmax;
+    struct Frame { uint32_t ref; int state; uint32_t e0; };
+    std::vector<Frame> st;
+    for (uint32_t ty = 0; ty < gty; ++ty) {
+        for (uint32_t tx = 0; tx < gtx; ++tx) {
+            double alen2 = 0.0;
+            for (int i = 0; i < 3; ++i) {
+                b.a0[i] = cam.cam_center[i];
+                b.ax[i] = (double)cam.pixel00[i] + (double)cam.pixel_delta_u[i] * (8.0 * tx + 3.5) + (double)cam.pixel_delta_v[i] * (8.0 * ty + 3.5) - b.a0[i];
+                alen2 += b.ax[i] * b.ax[i];
+            }
+            b.alen = std::sqrt(alen2);
+            if (!(b.alen > 1e-12) || !std::isfinite(b.alen)) continue; // degenerate camera: from the root
+            for (int i = 0; i < 3; ++i) b.ax[i] /= b.alen;
+            // does any sphere of leaf `ref` survive?
+            auto leaf_reached = [&](uint32_t ref) {
+                const uint32_t first = ref & 0x00ffffffu, cnt = (ref >> 24) & 0x7fu;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const rtmi_object& o = objects[bvh.slot_object[first + k]];
+                    const double c[3] = {o.center[0], o.center[1], o.center[2]}, r = std::fabs((double)o.radius);
+                    const double l = std::sqrt((c[0] - b.a0[0]) * (c[0] - b.a0[0]) + (c[1] - b.a0[1]) * (c[1] - b.a0[1]) + (c[2] - b.a0[2]) * (c[2] - b.a0[2])) + b.r_lens;
+                    if (b.reaches(c, r + b.margin(l, r))) return true;
+                }
+                return false;
+            };
+            // can the box of child k of node n hold such a sphere?  (its bounding ball: every sphere below lies inside the box)
+            auto box_reached = [&](const rtmi_bvh_node& nd, int k) {
+                const double c[3] = {nd.ctr[k][0], nd.ctr[k][1], nd.ctr[k][2]};
+                const double rb = std::sqrt((double)nd.half[k][0] * nd.half[k][0] + (double)nd.half[k][1] * nd.half[k][1] + (double)nd.half[k][2] * nd.half[k][2]);
+                if (!std::isfinite(rb)) return true;
+                const double l = std::sqrt((c[0] - b.a0[0]) * (c[0] - b.a0[0]) + (c[1] - b.a0[1]) * (c[1] - b.a0[1]) + (c[2] - b.a0[2]) * (c[2] - b.a0[2])) + rb + b.r_lens;
+                return b.reaches(c, rb + b.margin(l, 0.0)); // (r = 0: the square-root form bounds e for every radius below)
+            };
+            // entry(ref) = the lowest common ancestor of the leaves with a surviving sphere below ref (kNoWalkRef: none), iteratively
+            st.clear();
+            st.push_back({walk_root, 0, kNoWalkRef});
+            uint32_t ret = kNoWalkRef;
+            while (!st.empty()) {
+                Frame& f = st.back();
+                if (f.ref & kLeafBit) {
+                    ret = leaf_reached(f.ref) ? f.ref : kNoWalkRef;
+                    st.pop_back();
+                    continue;
+                }
+                const rtmi_bvh_node& nd = bvh.nodes[f.ref];
+                if (f.state == 0) {
+                    f.state = 1;
+                    if (box_reached(nd, 0)) { st.push_back({nd.child[0], 0, kNoWalkRef}); continue; }
+                    ret = kNoWalkRef;
+                }
+                if (f.state == 1) {
+                    f.e0 = ret;
+                    f.state = 2;
+                    if (box_reached(nd, 1)) { st.push_back({nd.child[1], 0, kNoWalkRef}); continue; }
+                    ret = kNoWalkRef;
+                }
+                const uint32_t e1 = ret, e0 = f.e0, self = f.ref;
+                ret = (e0 != kNoWalkRef && e1 != kNoWalkRef) ? self : (e0 != kNoWalkRef ? e0 : e1);
+                st.pop_back();
+            }
+            entries[(size_t)ty * gtx + tx] = ret;
+        }
+    }
+}
+
+} // namespace rtmi
+
 extern "C" int rtmi_bvh_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size,
                               rtmi_bvh_node* nodes_out, uint32_t* n_nodes, uint32_t* slots_out, uint32_t* root_ref,
                               uint32_t* depth, float* pad_classes_out, uint32_t* n_classes, float* pad_eps,
@@ -769,5 +925,38 @@ extern "C" int rtmi_bvh_build_passes(const rtmi_object* objects, uint32_t n_obje
     if (nodes_out && !bvh.nodes.empty()) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtmi_bvh_node));
     if (slots_out && n_objects) std::memcpy(slots_out, bvh.slot_object.data(), n_objects * sizeof(uint32_t));
     if (pad_classes_out) std::memcpy(pad_classes_out, bvh.pad_classes, sizeof(bvh.pad_classes));
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_tile_entries_build(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size,
+                                       uint32_t bvh_passes, uint32_t* entries_out, uint32_t* n_tiles) {
+    if (!camera || (n_objects && !objects)) {
+        set_error("rtmi_tile_entries_build: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    for (uint32_t i = 0; i < n_objects; ++i) {
+        const rtmi_object& o = objects[i];
+        if (!std::isfinite(o.center[0]) || !std::isfinite(o.center[1]) || !std::isfinite(o.center[2]) || !std::isfinite(o.radius)) {
+            set_error("rtmi_tile_entries_build: object with a non-finite centre or radius");
+            return RTMI_ERR_BAD_ARG;
+        }
+    }
+    try {
+        Bvh bvh;
+        build_bvh(objects, n_objects, leaf_size ? leaf_size : (n_objects > 0x2000u ? 4u : 2u),
+                  bvh_passes ? bvh_passes - 1u : default_bvh_passes(n_objects), bvh);
+        uint32_t pre[4], n_pre = 0;
+        const uint32_t walk_root = peel_top_leaves(bvh, pre, n_pre);
+        std::vector<uint32_t> entries;
+        build_tile_entries(*camera, objects, bvh, walk_root, entries);
+        if (n_tiles) *n_tiles = static_cast<uint32_t>(entries.size());
+        if (entries_out && !entries.empty()) std::memcpy(entries_out, entries.data(), entries.size() * sizeof(uint32_t));
+    } catch (const std::bad_alloc&) {
+        set_error("rtmi_tile_entries_build: out of host memory");
+        return RTMI_ERR_OOM;
+    } catch (...) {
+        set_error("rtmi_tile_entries_build: unexpected exception");
+        return RTMI_ERR_INTERNAL;
+    }
     return RTMI_OK;
 }

@@ -17,6 +17,7 @@ static_assert(sizeof(rtmi_camera) == 100, "14 POD fields of RayTracingCore (refe
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kMaxPadClasses = 4;
 constexpr uint32_t kMaxLeafSize = 4;
+constexpr uint32_t kNoWalkRef = 0xffffffffu; // "nothing to walk": every leaf was peeled, or (camera entries) the tile's beam meets no sphere
 
 // The counter streams are keyed by a bijective mix of the caller's 64-bit seed (the finaliser of splitmix64, Steele,
 // Lea & Flood, OOPSLA'14): seeds that differ in one bit, or only in their high word, give unrelated key words
@@ -53,5 +54,7 @@ void set_error(const std::string& msg);
 inline uint32_t default_bvh_passes(uint32_t n_objects) { return n_objects > 0x2000u ? 0u : 2u; }
 void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, uint32_t optimise_passes, Bvh& out);
 bool pad_refine_pays(const float (*classes)[8], uint32_t n_classes, float pad_eps);
+uint32_t peel_top_leaves(const Bvh& bvh, uint32_t pre[4], uint32_t& n_pre);
+void build_tile_entries(const rtmi_camera& cam, const rtmi_object* objects, const Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& entries);
 
 } // namespace rtmi

@@ -39,6 +39,9 @@ struct RtmiLaunch {
     uint32_t n_slots, n_mats, n_nodes, root_ref;
     uint32_t pre_leaf[4];     // leaves hanging off the top of the tree (the ground sphere): tested at segment set-up
     uint32_t n_pre_leaves;    // root_ref == kNoWalk: they were the whole tree
+    // camera rays: where the walks of the samples of each 8x8 tile of the WHOLE image start (tile = (gy / 8) * gtiles_x + px / 8): a
+    // node or leaf reference in the kernel variant's format, kStackEnd = the tile's beam meets no sphere of the tree; NULL: the root
+    const uint32_t* tile_entry;
     float pad_classes[kMaxPadClasses][8];
     uint32_t n_pad_classes;
     float pad_eps, pad_floor;
@@ -47,7 +50,6 @@ struct RtmiLaunch {
     // LDS carve-up (byte offsets)
     uint32_t lds_spheres, lds_aux, lds_mats, lds_nodes, lds_stack, stack_depth, lds_att, lds_pool;
     uint32_t lds_top_nodes;   // HBM-resident trees: this many breadth-first nodes (48-byte records) start the LDS segment
-    uint32_t lds_ahead;       // packed-chain launches: byte offset of the per-lane slots of primary rays generated ahead (0: none), see the GEN phase
     // image rows handled by this launch
     uint32_t y_first, block_rows, block_stride, n_local_rows;
     uint32_t x_first, x_end, local_w; // columns [x_first, x_end) of every row (rtmi_render_rect; whole rows: 0, W, W); local_w = x_end - x_first

@@ -116,7 +116,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
     Trav t{};
     t.cur = kStackEnd; // "not walking" (see the traversal loop)
     uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0, st_item0 = 0;
-    uint32_t parked = 0; // packed-chain launches: a primary ray for this lane's next sample is in its LDS slot (GEN phase)
     PF_DECL
     PB_DECL
 
@@ -218,8 +217,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
         t.tbest = __builtin_inff();
         t.best = ~0u;
         t.sp = lds0 + P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT) + sp_stride; // entry 1 (entry 0: the sentinel)
-        if (ACCEL == RTMI_ACCEL_BVH) {
-            t.cur = P.root_ref;
+        if (ACCEL == RTMI_ACCEL_BVH) { // (t.cur, where the walk starts, was set by whoever made the segment: the root, or a camera ray's entry)
             t.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
             PF_MARK(17);
             t.oinv = mk(-(o.x * t.inv.x), -(o.y * t.inv.y), -(o.z * t.inv.z));
@@ -356,55 +354,47 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
         ISA_MARK("gen");
         PB(1, phase == PH_GEN);
         // (a gate on this branch -- run it only when K lanes need a primary ray or one has waited T rounds -- was measured
-        // on configs 3, 4 and 5: +-0 at best, slower from K = 8 up; profiles/r03_gating_experiment.txt)
-        // RayTracingCore::get_ray for sample `gs` of this lane's pixel: the two defocus-disk offsets, the direction pixel_sample - origin
-        // and the stream position behind the draws it took (nothing of the lane's live path state is touched)
-        auto gen_ray = [&](uint32_t gs, float& dx, float& dy, V3& dir, uint32_t& k_after) {
+        // on configs 3, 4 and 5: +-0 at best, slower from K = 8 up; profiles/r03_gating_experiment.txt.  Primary rays generated
+        // AHEAD into LDS slots whenever some lane needs one now -- rounds 4 and 5 -- measured -0.6 % switched on against off, and
+        // round 6's same-box A/B of whole libraries showed what its code costs the packed-chain variant either way: +3 % on the
+        // config-5 frame, profiles/r06_r4_vs_r5.txt; it is out of the source)
+        // where a camera ray's walk starts: the entry of its 8x8 tile of the image (host: build_tile_entries -- the lowest common
+        // ancestor of every sphere the tile's beam can meet, kStackEnd when it meets none), else the root
+        auto camera_entry = [&](uint32_t px, uint32_t gy) -> uint32_t {
+            if (ACCEL != RTMI_ACCEL_BVH) return 0u;
+            return P.tile_entry != nullptr ? P.tile_entry[(gy >> 3) * P.gtiles_x + (px >> 3)] : P.root_ref;
+        };
+        if (phase == PH_GEN) {
             const uint32_t gy = fdiv(rng.pixel, P.div_w), px = rng.pixel - gy * W; // (rng.pixel = gy * W + px came with the work item)
-            Rng r2;
-            r2.pixel = rng.pixel;
-            r2.sample = gs;
-            r2.k = 2;
-            Blk gb = rng_block(r2, 0u, P.seed); // draws 0,1: pixel jitter; 2,3: first defocus-disk attempt
+            t.cur = camera_entry(px, gy); // (first: the load is in flight behind the ray's arithmetic, its address registers are free again)
+            rng.k = 0;
+            rng.sample = s;
+            Blk gb = rng_block(rng, 0u, P.seed); // draws 0,1: pixel jitter; 2,3: first defocus-disk attempt
             const float offx = draw_centered(gb.w0);
             const float offy = draw_centered(gb.w1);
+            rng.k = 2;
             const V3 du = ld3(P.cam.pixel_delta_u), dv = ld3(P.cam.pixel_delta_v);
             const V3 pixel_sample =
                 vadd(vadd(ld3(P.cam.pixel00), vscale(du, (float)px + offx)), vscale(dv, (float)gy + offy));
             V3 origin = ld3(P.cam.cam_center);
-            dx = 0.0f;
-            dy = 0.0f;
             if (!(P.cam.defocus_angle <= 0.0f)) {
                 // random_vector_on_unit_disk, random.number.gen.hpp:35-42
-                dx = draw_pm1(gb.w2);
-                dy = draw_pm1(gb.w3);
-                r2.k = 4;
+                float dx = draw_pm1(gb.w2), dy = draw_pm1(gb.w3);
+                rng.k = 4;
                 ISA_MARK("gen-disk-retry");
                 PF_MARK(1);
                 while (!(vdot(mk(dx, dy, 0.0f), mk(dx, dy, 0.0f)) < 1.0f)) { // two attempts per further block
                     PB(2, true);
-                    if ((r2.k & 3u) == 0u) gb = rng_block(r2, r2.k >> 2, P.seed);
-                    dx = draw_pm1((r2.k & 3u) ? gb.w2 : gb.w0);
-                    dy = draw_pm1((r2.k & 3u) ? gb.w3 : gb.w1);
-                    r2.k += 2u;
+                    if ((rng.k & 3u) == 0u) gb = rng_block(rng, rng.k >> 2, P.seed);
+                    dx = draw_pm1((rng.k & 3u) ? gb.w2 : gb.w0);
+                    dy = draw_pm1((rng.k & 3u) ? gb.w3 : gb.w1);
+                    rng.k += 2u;
                 }
                 PF_MARK(20);
                 ISA_MARK("gen-tail");
                 origin = vadd(vadd(ld3(P.cam.cam_center), vscale(ld3(P.cam.defocus_disk_u), dx)),
                               vscale(ld3(P.cam.defocus_disk_v), dy));
             }
-            dir = vsub(pixel_sample, origin);
-            k_after = r2.k;
-        };
-        // the lens point of get_ray from its two offsets (core.cc:226-231)
-        auto ray_origin = [&](float dx, float dy) -> V3 {
-            V3 origin = ld3(P.cam.cam_center);
-            if (!(P.cam.defocus_angle <= 0.0f))
-                origin = vadd(vadd(ld3(P.cam.cam_center), vscale(ld3(P.cam.defocus_disk_u), dx)), vscale(ld3(P.cam.defocus_disk_v), dy));
-            return origin;
-        };
-        auto start_sample = [&](float dx, float dy, V3 dir, uint32_t k_after) {
-            rng.k = k_after;
             depth_left = P.cam.maxdepth;
             natt = 0;
             run_n = 0;
@@ -412,54 +402,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             if (depth_left == 0) {
                 // compute_color(depth == 0) returns 0 at once (core.cc:238-240): the sample is black
                 t.best = kBlackSample; // marker read by SHADE: finish the sample without tracing
+                if (ACCEL == RTMI_ACCEL_BVH) t.cur = kStackEnd;
                 phase = PH_SHADE;
             } else {
-                t.o = ray_origin(dx, dy);
-                t.d = dir;
+                t.o = origin;
+                t.d = vsub(pixel_sample, origin);
                 phase = PH_BEGIN;
             }
-        };
-        if (PACKED && P.lds_ahead != 0u) {
-            // Primary rays generated ahead (packed-chain launches whose LDS has room for the slots: the box of config 5, where this
-            // branch -- ~130 instructions -- ran in every other round for ONE or two lanes: 79 segments to a sample, 64 lanes).  A
-            // primary ray is a pure function of (pixel, sample): whenever some lane has to generate one NOW, every lane that is
-            // inside a sample and has none in store generates the ray of its item's NEXT sample alongside and parks it -- lens
-            // offsets, direction, stream position: 21 bytes of LDS a lane -- and a lane that starts a sample with a ray in store
-            // takes it.  Round 4 measured it (+1.6 % on the box, bit-identical) and did not ship it because the S-RTOW scene has no
-            // room for the slots; it is a per-variant switch now (VERDICT r4 #3a).
-            float* slot = reinterpret_cast<float*>(lds_raw + P.lds_ahead) + threadIdx.x;
-            lds_u8* kslot = (lds_u8*)(uintptr_t)(lds0 + P.lds_ahead + 20u * blockDim.x + threadIdx.x);
-            const bool now = phase == PH_GEN && parked == 0u;
-            if (ballot(now) != 0ull) {
-                const bool ahead = parked == 0u && (phase == PH_BEGIN || phase == PH_TRAV || phase == PH_SHADE) && s + 1u < s_end;
-                if (now || ahead) {
-                    float dx, dy;
-                    V3 dir;
-                    uint32_t k_after;
-                    gen_ray(now ? s : s + 1u, dx, dy, dir, k_after);
-                    if (now) {
-                        start_sample(dx, dy, dir, k_after);
-                    } else {
-                        slot[0] = dx;
-                        slot[blockDim.x] = dy;
-                        slot[2u * blockDim.x] = dir.x;
-                        slot[3u * blockDim.x] = dir.y;
-                        slot[4u * blockDim.x] = dir.z;
-                        *kslot = (uint8_t)k_after;
-                        parked = k_after > 255u ? 0u : 1u; // (a stream position past 255 -- 125 rejected disk points in a row -- is not parked)
-                    }
-                }
-            }
-            if (phase == PH_GEN && parked != 0u) {
-                parked = 0u;
-                start_sample(slot[0], slot[blockDim.x], mk(slot[2u * blockDim.x], slot[3u * blockDim.x], slot[4u * blockDim.x]), (uint32_t)*kslot);
-            }
-        } else if (phase == PH_GEN) {
-            float dx, dy;
-            V3 dir;
-            uint32_t k_after;
-            gen_ray(s, dx, dy, dir, k_after);
-            start_sample(dx, dy, dir, k_after);
         }
         // every new segment of this round -- primary rays, scattered rays, resumed paths -- is set up here, once
         PF_MARK(1);
@@ -722,6 +671,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                     } else {
                         t.o = p;
                         t.d = sd;
+                        if (ACCEL == RTMI_ACCEL_BVH) t.cur = P.root_ref;
                         phase = PH_BEGIN; // set up before the next traversal, together with the new primary rays
                     }
                 }

@@ -206,15 +206,12 @@ def test_packed_and_run_length_attenuation_chains(pkg, ob, rtow, gpu):
     g = np.load(os.path.join(GOLDEN, "cornell_counter_48x48x32.npz"))
     ccam = pkg.camera_setup(pkg.camera_params(**json.loads(str(g["camera"]))))
     for tun, packed in ((None, True), (dict(chain_mode=1), False), (dict(sample_buf_mb=1), True), (dict(chunk_samples=-1), True),
-                        (dict(block_lanes=512, chunk_samples=5), True), (dict(gen_ahead=1), True), (dict(gen_ahead=1, chunk_samples=3), True),
+                        (dict(block_lanes=512, chunk_samples=5), True), (dict(gen_ahead=1, chunk_samples=3), True),
                         (dict(chunk_samples=2), True)):
         for accel, _ in _both(pkg):
             with pkg.Scene(ccam, g["objects"], g["materials"], accel=accel, tuning=tun) as s:
                 assert (s.launch_info()["packed_chains"] > 0) == packed
-                # packed-chain launches generate primary rays ahead into LDS slots where these fit (round 5): on by default for the
-                # scan of this box, off on request, never for run-length encoded chains
-                if accel == pkg.ACCEL_BRUTE:
-                    assert s.launch_info()["gen_ahead"] == (1 if packed and not (tun or {}).get("gen_ahead") else 0), (tun, s.launch_info())
+                assert s.launch_info()["gen_ahead"] == 0  # (round 5's primary rays generated ahead are out again; the knob is ignored)
                 rgb, rgba = s.render_rows(0, ccam.img_height, int(g["seed"]))
                 part, _ = s.render_rows(7, 19, int(g["seed"]))
                 assert s.launch_info()["packed_chain_fallbacks"] == 0  # what was launched is what the scene is eligible for
@@ -866,6 +863,86 @@ def test_cost_ordered_tiles_and_sequential_bands_do_not_change_the_image(pkg, ob
     with pytest.raises(pkg.RtmiError) as err:
         pkg.Scene(cam, *rtow, tuning=dict(tile_order=3))
     assert err.value.code == pkg.RTMI_ERR_BAD_ARG
+
+
+def test_record_buffers_of_several_scenes_never_exceed_the_device(pkg, rtow, gpu):
+    """scenes keep their sample-record buffers between calls, and the cap on one band's records used to come from the
+    device's TOTAL memory (a third of it), whatever else lived there.  Several scenes on one device whose record buffers together
+    exceed it: every frame must still come out (the later scenes in more, smaller bands, or with whole-pixel work items), bit
+    for bit the same, or the library must answer RTMI_ERR_OOM -- it never aborts (include/rtmi.h: "never throws, never aborts")."""
+    import hashlib
+    torch = gpu
+    _free, total = torch.cuda.mem_get_info(0)
+    kw = dict(image_width=1920, samples_per_pixel=2048, max_depth=50)
+    cam = pkg.camera_setup(pkg.camera_params(**kw))
+    per_scene = cam.img_width * cam.img_height * 2048 * 16  # 68 GB of records for the frame in one band
+    n = int(total // per_scene) + 2
+    scenes, digests, bands = [], [], []
+    try:
+        for i in range(n):
+            try:
+                s = pkg.Scene(cam, *rtow)
+                scenes.append(s)
+                _, rgba = s.render_rows(0, cam.img_height, 11, rgb=False)
+            except pkg.RtmiError as e:
+                assert e.code == pkg.RTMI_ERR_OOM, e
+                continue
+            li = s.launch_info()
+            digests.append(hashlib.sha256(rgba.tobytes()).hexdigest())
+            bands.append((li["bands"], li["whole_pixel_fallbacks"], li["reband_retries"]))
+        assert len(digests) >= 2 and len(set(digests)) == 1, (digests, bands)
+        assert bands[0][0] == 1 and (bands[-1][0] > 1 or bands[-1][1] > 0 or len(digests) < n), bands
+    finally:
+        for s in scenes:
+            s.close()
+
+
+def test_camera_entries_do_not_change_the_image(pkg, ob, rtow, gpu):
+    """rtmi_tuning::cam_entry (0.6): the walks of camera rays start at their image tile's entry (host table, see
+    tests/test_host_cpu.py::test_camera_tile_entries_keep_the_walk_exact) instead of the root.  Same frame as the oracle's linear
+    scan with the table on (default) and off, trees in LDS and in HBM, whole-pixel items, rows and rectangles that do not start on
+    a tile (the table is indexed by the ABSOLUTE pixel), sharded row blocks; fewer box tests with it, and exactly the box and sphere
+    tests of the oracle's walk that follows the same table."""
+    kw = dict(image_width=200, samples_per_pixel=6, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    W, H = cam.img_width, cam.img_height
+    want, want8 = ob.render_rect_counter(ocam, *rtow, 61, 0, 0, W, H, nthreads=8)
+    tests = {}
+    for tun in (dict(), dict(cam_entry=1), dict(force_hbm_scene=1, cam_entry=2), dict(force_hbm_scene=1), dict(chunk_samples=-1),
+                dict(tile_order=2, bands=3), dict(chain_mode=1, block_lanes=512)):
+        with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=tun or None) as s:
+            on = tun.get("cam_entry", 0) == 2 or (tun.get("cam_entry", 0) == 0 and not tun.get("force_hbm_scene"))  # (default: trees in LDS)
+            li = s.launch_info()
+            assert li["cam_entry"] == (1 if on else 0) and (li["entry_build_us"] > 0) == on, (tun, li)
+            rgb, rgba = s.render_rows(0, H, 61)
+            st = s.stats()
+            _assert_frames_equal(rgb, want)
+            assert np.array_equal(rgba, want8)
+            bvh = s.bvh()
+            assert (bvh["entries"] is not None) == on
+            if tun == dict() or tun == dict(cam_entry=1) or "force_hbm_scene" in tun:
+                _, _, c = ob.render_rect_counter(ocam, *rtow, 61, 0, 0, W, H, nthreads=8, counters=True, bvh=bvh)
+                assert st["segments"] == c["segments"]
+                assert abs(st["node_tests"] - c["node_tests"]) <= 1e-3 * c["node_tests"], (tun, st, c)
+                assert abs(st["sphere_tests"] - c["sphere_tests"]) <= 1e-3 * c["sphere_tests"], (tun, st, c)
+                tests[on, "force_hbm_scene" in tun] = st["node_tests"]
+            part, _ = s.render_rows(5, 77, 61)
+            _assert_frames_equal(part, want[5:77])
+            rect, _ = s.render_rect(13, 3, 150, 88, 61)
+            _assert_frames_equal(rect, want[3:88, 13:150])
+    assert tests[True, False] < 0.9 * tests[False, False] and tests[True, True] < 0.9 * tests[False, True], tests
+    # a table that says "no walk" for the sky and a leaf for a lone sphere: one sphere over a ground, seen from afar
+    objs, mats = arrays([((0.0, -1000.0, 0.0), 1000.0, (0, (0.5, 0.5, 0.5, 0.0))), ((0.0, 1.0, 0.0), 1.0, (2, (1.5, 0.0, 0.0, 0.0))),
+                         ((-3.0, 0.4, 1.0), 0.4, (1, (0.8, 0.7, 0.6, 0.2))), ((2.5, 0.3, -1.0), 0.3, (0, (0.2, 0.5, 0.7, 0.0)))] +
+                        [((0.7 * i - 6.0, 0.15, 3.0 + 0.1 * (i % 3)), 0.15, (i % 3, (0.6, 0.6, 0.6, 0.1) if i % 3 != 2 else (1.4, 0, 0, 0))) for i in range(30)])
+    kw = dict(image_width=120, samples_per_pixel=5, max_depth=20, defocus_angle=1.5)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    want, _ = ob.render_rect_counter(ocam, objs, mats, 3, 0, 0, cam.img_width, cam.img_height, nthreads=8)
+    with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH) as s:
+        ent = s.bvh()["entries"]
+        assert (ent == 0xffffffff).any() and ((ent & 0x80000000) != 0).any()
+        rgb, _ = s.render_rows(0, cam.img_height, 3)
+    _assert_frames_equal(rgb, want)
 
 
 def test_differential_fuzz_slice(pkg, ob, gpu):

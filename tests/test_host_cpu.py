@@ -87,7 +87,7 @@ def test_scene_create_argument_errors(pkg):
     info = pkg.LaunchInfo()
     info.struct_size = C.sizeof(pkg.LaunchInfo)
     assert pkg.lib().rtmi_scene_get_launch_info(None, C.byref(info)) == pkg.RTMI_ERR_BAD_ARG
-    assert C.sizeof(pkg.LaunchInfo) == 68  # 40 in version 0.3, 52 in 0.4: the struct grows at its end, struct_size tells the library what fits
+    assert C.sizeof(pkg.LaunchInfo) == 88  # 40 in version 0.3, 52 in 0.4, 68 in 0.5: the struct grows at its end, struct_size tells the library what fits
     pkg.lib().rtmi_scene_destroy(None)  # no-op
 
 
@@ -133,7 +133,7 @@ def test_frame_create_argument_errors(pkg):
 
 
 def test_tuning_struct_layout_and_unknown_knobs(pkg):
-    assert C.sizeof(pkg.Tuning) == 76 and C.sizeof(pkg.SceneOptions) == 40  # (64 in 0.4: the struct grows at its end)
+    assert C.sizeof(pkg.Tuning) == 92 and C.sizeof(pkg.SceneOptions) == 40  # (64 in 0.4, 76 in 0.5: the struct grows at its end)
     with pytest.raises(KeyError):
         pkg.make_tuning(no_such_knob=1)
     header = open(os.path.join(ROOT, "include", "rtmi.h")).read()
@@ -211,6 +211,43 @@ def test_bvh_builder_invariants(pkg, rtow):
             assert area(opt) <= area(plain) * (1 + 1e-6)
 
 
+def test_camera_tile_entries_keep_the_walk_exact(pkg, ob, rtow):
+    """rtmi_tuning::cam_entry (0.6): camera rays start their walk at their 8x8 tile's entry -- the lowest common ancestor of every
+    sphere the tile's beam (lens disk x tile rectangle) can meet -- or do not walk at all.  The table is host geometry
+    (rtmi_tile_entries_build, no device): the oracle's instrumented walk FOLLOWING it must give the frame of the oracle's linear
+    scan, float for float: S-RTOW under several lenses and cameras (inside the glass sphere, grazing the ground, far away), random
+    worlds of the differential fuzz (negative radii, huge and tiny scales, nested spheres), and it must skip work."""
+    fuzz_world = pkg.workloads.fuzz_world
+    cases = []
+    for kw in (dict(image_width=160, samples_per_pixel=3), dict(image_width=160, samples_per_pixel=2, defocus_angle=0.0),
+               dict(image_width=96, samples_per_pixel=2, defocus_angle=8.0, focus_distance=4.0),
+               dict(image_width=96, samples_per_pixel=2, lookfrom=(0.0, 1.0, 0.3), lookat=(4.0, 1.0, 0.0), vertical_fov=70.0),
+               dict(image_width=96, samples_per_pixel=2, lookfrom=(6.0, 0.21, 6.0), lookat=(0.0, 0.2, 0.0), defocus_angle=2.0),
+               dict(image_width=64, samples_per_pixel=2, lookfrom=(900.0, 300.0, 500.0), vertical_fov=2.0, focus_distance=1000.0)):
+        cases.append((*rtow, dict(max_depth=12, **kw), 2))
+    rng = np.random.default_rng(66)
+    for case in range(40):
+        objs, mats, kw = fuzz_world(rng, case)
+        cases.append((objs, mats, dict(kw, max_depth=min(kw["max_depth"], 8)), int(rng.choice([1, 2, 4]))))
+    skipped = walked = 0
+    for objs, mats, kw, leaf in cases:
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        W, H = cam.img_width, cam.img_height
+        want, _ = ob.render_rect_counter(ocam, objs, mats, 9, 0, 0, W, H, nthreads=8)
+        bvh = pkg.bvh_build(objs, leaf)
+        bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
+        _, _, c0 = ob.render_rect_counter(ocam, objs, mats, 9, 0, 0, W, H, nthreads=8, counters=True, bvh=bvh)
+        ent = pkg.tile_entries_build(cam, objs, leaf)
+        assert ent.shape == ((H + 7) // 8, (W + 7) // 8)
+        got, _, c1 = ob.render_rect_counter(ocam, objs, mats, 9, 0, 0, W, H, nthreads=8, counters=True, bvh=dict(bvh, entries=ent))
+        a, b = np.nan_to_num(got, nan=-1.0).view(np.uint32), np.nan_to_num(want, nan=-1.0).view(np.uint32)
+        assert np.array_equal(a, b), (kw, int((a != b).any(axis=-1).sum()))
+        assert c1["segments"] == c0["segments"] and c1["node_tests"] <= c0["node_tests"]
+        skipped += c0["node_tests"] - c1["node_tests"]
+        walked += c0["node_tests"]
+    assert skipped > 0.05 * walked  # (S-RTOW at 1080p: camera rays 8.9 -> 2.0 node trips each, tools/wave_replay.py)
+
+
 @pytest.mark.parametrize("height,block,world", [(1080, 8, 1), (1080, 8, 8), (675, 8, 2), (675, 8, 4), (225, 16, 8),
                                                 (7, 8, 4), (54, 8, 3)])
 def test_row_block_sharding_covers_every_row_once(pkg, height, block, world):
@@ -250,7 +287,7 @@ def test_header_is_plain_c_and_every_prototype_is_exported(pkg, tmp_path):
     src = tmp_path / "hc.c"
     src.write_text('#include "rtmi.h"\n'
                    'int main(void) { return (sizeof(rtmi_object) == 24 && sizeof(rtmi_material) == 20 && sizeof(rtmi_camera) == 100\n'
-                   '                         && sizeof(rtmi_bvh_node) == 64 && sizeof(rtmi_launch_info) == 68 && sizeof(rtmi_tuning) == 76) ? 0 : 1; }\n')
+                   '                         && sizeof(rtmi_bvh_node) == 64 && sizeof(rtmi_launch_info) == 88 && sizeof(rtmi_tuning) == 92) ? 0 : 1; }\n')
     exe = tmp_path / "hc"
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
