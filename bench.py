@@ -108,6 +108,8 @@ def parse_args(argv=None):
     ap.add_argument("--depth", type=int, default=0, help="override the config's bounce limit (diagnostics)")
     ap.add_argument("--accel", choices=("auto", "bvh", "brute"), default="auto",
                     help="auto = the library's own choice (RTMI_ACCEL_AUTO: BVH walk above 24 spheres, the reference's linear scan below)")
+    ap.add_argument("--shard-plan", choices=("mod", "cost"), default="mod",
+                    help="N > 1: row block b -> rank b mod N (default), or dealt out by the scene's cost map (rtmi_shard_plan)")
     ap.add_argument("--single-process", action="store_true",
                     help="one process, N devices, through rtmi_frame_* (RCCL inside librtmi.so)")
     ap.add_argument("--force-dist", action="store_true",
@@ -358,8 +360,19 @@ def main(argv=None):
         scene = pkg.Scene(cam, objs, mats, accel=accel, device=local_rank)
         torch.cuda.synchronize(dev)
         scene_setup_ms = (time.perf_counter() - t_setup) * 1e3
-        plan = pkg.RowShardPlan(H, BLOCK_ROWS, world)
-        y_first, n_blocks, rows = plan.shard(rank)
+        # row blocks -> ranks: block b -> rank b mod N, or (--shard-plan cost) by the scene's cost map, longest processing
+        # time first.  Every rank's probe counts the same integers; rank 0's costs travel all the same, so that no rank can disagree.
+        # (Measured on the one-GPU rehearsal, profiles/r06_shard_perf.txt: the two plans' slowest shards are 17.88 and 17.86 ms at
+        # N = 8 -- segment counts balance to 0.1 % and the shards stay 4 % apart -- so the default stays the plan of rounds 1-5.)
+        costs = scene.tile_costs() if (world > 1 and args.shard_plan == "cost") else None
+        bc = pkg.block_costs(costs, H, BLOCK_ROWS) if costs is not None else np.zeros((H + BLOCK_ROWS - 1) // BLOCK_ROWS, np.uint64)
+        if use_dist:
+            t_bc = torch.from_numpy(bc.astype(np.int64)).to(dev if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(t_bc, src=0)
+            bc = t_bc.cpu().numpy().astype(np.uint64)
+        plan = pkg.CostShardPlan(H, BLOCK_ROWS, world, bc if bc.any() else None)
+        my_blocks = plan.blocks(rank)
+        n_blocks, rows = len(my_blocks), plan.rows(rank)
         # one buffer per rank -- float RGB then RGBA8 (as bits) -- so that the frame travels in ONE collective
         n_px = plan.max_rows * W
         local = torch.zeros(n_px * 4, dtype=torch.float32, device=dev)
@@ -378,9 +391,10 @@ def main(argv=None):
             return f, f8
 
         def step():
-            if n_blocks:
-                scene.render_row_blocks_device(y_first, BLOCK_ROWS, world, n_blocks, RENDER_SEED, rgb.data_ptr(),
-                                               rgba.data_ptr(), stream)
+            if n_blocks and world == 1:
+                scene.render_row_blocks_device(0, BLOCK_ROWS, 1, n_blocks, RENDER_SEED, rgb.data_ptr(), rgba.data_ptr(), stream)
+            elif n_blocks:
+                scene.render_block_list_device(BLOCK_ROWS, my_blocks, RENDER_SEED, rgb.data_ptr(), rgba.data_ptr(), stream)
             if not use_dist:
                 return rgb[:H], rgba[:H]
             if dist.get_backend() != "nccl":  # rehearsal backend: stage through host memory
@@ -504,7 +518,8 @@ def main(argv=None):
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label} {len(objs)} spheres, {W}x{H}, {spp} spp, {depth} bounces, accel={args.accel}",
                        "baseline_config": f"configs[{int(args.config) - 1}]: {cfg['name']}",
-                       "sharding": f"interleaved {BLOCK_ROWS}-row blocks x{n_gpus}, 1 gather to rank 0",
+                       "sharding": (f"{BLOCK_ROWS}-row blocks dealt out by the scene's cost map (longest processing time first, rtmi_shard_plan) x{n_gpus}, 1 gather to rank 0"
+                                    if (not args.single_process and world > 1 and bc.any()) else f"interleaved {BLOCK_ROWS}-row blocks x{n_gpus}, 1 gather to rank 0"),
                        "launcher": launcher,
                        "resident": "scene+BVH in HBM before the timed region; frame stays in HBM"},
             "rccl_ranks": rccl_ranks,
@@ -578,8 +593,10 @@ def main(argv=None):
         li = scene.launch_info() if scene is not None else {}
         if li:
             out["launch"] = {"bands": li.get("bands"), "tile_order": li.get("tile_order"), "probe_us": li.get("probe_us"),
+                             "cam_entry": li.get("cam_entry"), "entry_build_us": li.get("entry_build_us"),
                              "note": "the most recent call: bands of rows it was rendered in, 8x8 tiles handed out costliest first (1) or row "
-                                     "by row (0), duration of the scene's one cost probe launch (inside first_frame_ms)"}
+                                     "by row (0), duration of the scene's one cost probe launch and host time of its table of camera-ray "
+                                     "entries (both inside scene_setup_ms since round 6)"}
         chain_words = li.get("packed_chains", 0) if li.get("packed_chain_fallbacks", 0) == 0 else 0
         chain_bytes = 0.0
         if chain_words:

@@ -107,7 +107,7 @@ typedef struct rtmi_tuning {
     uint32_t struct_size;       /* = sizeof(rtmi_tuning) */
     uint32_t block_lanes;       /* lanes per workgroup, multiple of 64 (default 768: 2 x 768 per CU = 6 waves per SIMD) */
     uint32_t blocks_per_cu;     /* cap on resident workgroups per CU (default: the occupancy query) */
-    uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 52) */
+    uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 52; 56 for trees staged into LDS whose camera rays have entries) */
     uint32_t pad_mode;          /* BVH box pad per ray segment: 1 = the class pad of rounds 1-3 (from the farthest centre of each
                                  * radius class), 2 = that pad bounded by the reach of the segment, 0 = default: 2 on scenes
                                  * much wider than their spheres (where it pays), else 1; same image in every mode.
@@ -142,7 +142,10 @@ typedef struct rtmi_tuning {
                                  * sphere the tile's beam (lens disk x tile rectangle on the focus plane) can meet, nowhere when it meets
                                  * none -- instead of the root: 0 = for trees staged into LDS (measured: -3.2 % on the 1080p S-RTOW frame,
                                  * +2.7 % on the HBM-resident 100k-sphere tree, whose top levels are the cheap ones), 1 = off, 2 = always */
-    uint32_t walk_start;        /* where the walks of scattered rays start: 0 = default, 1 = always at the root */
+    uint32_t walk_start;        /* where the walks of scattered rays start: 0 = default -- on trees that stay in HBM, in the leaf of the sphere
+                                 * the ray was scattered off, the siblings hanging off the path above it pre-loaded on the stack as way
+                                 * records (two levels a record, in the node format); at the root for trees staged into LDS, whose
+                                 * 80 KiB have no room for the records --, 1 = always at the root */
     uint32_t stack_cap;         /* HBM-resident trees: entries of a lane's traversal stack kept in LDS (the rest of a deeper walk spills
                                  * to memory): 0 = default, n > 0 = n */
     uint32_t reserved6;
@@ -235,6 +238,24 @@ int rtmi_render_row_blocks_device(rtmi_scene* scene, uint32_t y_first, uint32_t 
                                   uint32_t n_blocks, uint64_t seed, void* d_rgb_linear_out, void* d_rgba8_out,
                                   void* hip_stream);
 
+/* Same over a LIST of row blocks (0.6; the cost-balanced shards of a multi-GPU frame, rtmi_shard_plan): block k of the call is
+ * image rows [blocks[k] * block_rows, + block_rows) clipped to the image, rendered into rows [k * block_rows, ...) of the dense
+ * slice.  block_rows must be a multiple of 8; only the last listed block may be clipped by the image's end.  The image does not
+ * depend on how rows are grouped into calls. */
+int rtmi_render_block_list_device(rtmi_scene* scene, uint32_t block_rows, const uint32_t* blocks, uint32_t n_blocks,
+                                  uint64_t seed, void* d_rgb_linear_out, void* d_rgba8_out, void* hip_stream);
+
+/* Row blocks -> ranks for a frame of `height` rows on `n_ranks` devices (0.6; host only).  block_cost = NULL: block b -> rank
+ * b mod n_ranks (rounds 1-5).  With costs (one per block of block_rows rows, e.g. the sums of rtmi_scene_get_tile_costs over
+ * the block's tiles): longest processing time first -- blocks in falling cost order, each to the rank with the least cost so far
+ * among those that hold fewer than ceil(n_blocks / n_ranks) blocks -- so that every rank's slice has the same size and the
+ * ranks' costs differ by a fraction of one block.  rank_of_block_out: ceil(height / block_rows) entries.  Deterministic. */
+int rtmi_shard_plan(uint32_t height, uint32_t block_rows, uint32_t n_ranks, const uint64_t* block_cost, uint32_t* rank_of_block_out);
+/* The scene's cost map: ray segments per 8x8 tile of the image from the 2-spp probe rtmi_scene_create makes for scenes whose
+ * tiles are handed out costliest first (rtmi_tuning::tile_order), row-major over ceil(W / 8) x ceil(H / 8) tiles; *n_tiles = 0
+ * when the scene made no probe.  costs_out may be NULL (count only). */
+int rtmi_scene_get_tile_costs(const rtmi_scene* scene, uint32_t* costs_out, uint32_t* n_tiles);
+
 /* ---- introspection ------------------------------------------------------------------------------------ */
 const char* rtmi_last_error(void);
 const char* rtmi_version(void);
@@ -292,6 +313,16 @@ int rtmi_bvh_build_passes(const rtmi_object* objects, uint32_t n_objects, uint32
 /* The scene's table of camera-ray entries (0.6; rtmi_tuning::cam_entry), in the format of rtmi_tile_entries_build below; *n_tiles = 0 when
  * the scene has none (camera rays walk from the root).  entries_out may be NULL (count only). */
 int rtmi_scene_get_tile_entries(const rtmi_scene* scene, uint32_t* entries_out, uint32_t* n_tiles);
+/* The scene's walk starts of scattered rays (0.6; rtmi_tuning::walk_start, HBM-resident trees): per sphere slot 16 words {reference the
+ * walk of a ray scattered off that sphere starts at, n, indices of the n way records pre-loaded on its stack, padding}; way
+ * records are the nodes rtmi_scene_get_bvh returns BEHIND the tree's own (two sibling boxes of the path per record, in the node
+ * format).  *n_slots = 0 when every walk starts at the root.  records_out may be NULL (count only). */
+int rtmi_scene_get_walk_starts(const rtmi_scene* scene, uint32_t* records_out, uint32_t* n_slots);
+/* Host-only (0.6): the tree of rtmi_bvh_build_passes for the same arguments with the way records behind its nodes, and the start
+ * records (16 words per slot) of rtmi_scene_get_walk_starts.  nodes_out needs room for 3 * n_objects + 2 records, records_out for
+ * 16 * n_objects words; any output may be NULL. */
+int rtmi_walk_starts_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, uint32_t bvh_passes,
+                           rtmi_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* n_tree_nodes_out, uint32_t* records_out);
 /* Host-only (0.6): the table of camera-ray entries rtmi_scene_create builds for this camera and these objects (rtmi_tuning::cam_entry) --
  * per 8x8 tile of the image, row-major over ceil(W / 8) x ceil(H / 8) tiles, the reference (rtmi_bvh_node::child format, of the tree
  * rtmi_bvh_build_passes returns for the same arguments) of the lowest common ancestor of the leaves of every sphere a sample of the
@@ -328,6 +359,9 @@ typedef struct rtmi_frame_timing {
  * kernels execute on a one-GPU box. */
 #define RTMI_FRAME_REHEARSAL 1u
 #define RTMI_FRAME_FORCE_RCCL 2u
+/* options->reserved[0] & RTMI_FRAME_COST_PLAN (0.6): the row blocks are dealt out to the devices by the scene's cost map
+ * (rtmi_shard_plan) instead of block b -> device b mod n -- where the scene has one and block_rows is a multiple of 8 */
+#define RTMI_FRAME_COST_PLAN 4u
 int rtmi_frame_create(const rtmi_camera* camera, const rtmi_object* objects, uint32_t n_objects,
                       const rtmi_material* materials, uint32_t n_materials, const rtmi_scene_options* options,
                       const int32_t* devices, uint32_t n_devices, uint32_t block_rows, rtmi_frame** out);

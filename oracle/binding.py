@@ -248,6 +248,13 @@ def render_rect_counter(cam, objs, mats, seed, x0, y0, x1, y1, nthreads=1, count
         nodes = np.ascontiguousarray(bvh["nodes"])
         slots = np.ascontiguousarray(bvh["slots"], dtype=np.uint32)
         set_tile_entries(bvh.get("entries"))  # (the camera-ray entries of the scene the tree came from, if it has any)
+        starts = bvh.get("walk_starts")  # (and the walk starts of its scattered rays; way records sit behind the tree's nodes)
+        L = lib()
+        L.orc_set_walk_starts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.orc_set_walk_starts.restype = None
+        if starts is not None:
+            starts = np.ascontiguousarray(starts, dtype=np.uint32)
+            L.orc_set_walk_starts(_ptr(starts), _ptr(slots), len(slots), len(objs))
         pc = np.ascontiguousarray(bvh["pad_classes"], dtype=np.float32).reshape(-1, 8)
         assert nodes.dtype.itemsize == 64
         rc = lib().orc_render_rect_counter_bvh(C.byref(cam), _ptr(objs), len(objs), _ptr(mats), len(mats),
@@ -255,6 +262,7 @@ def render_rect_counter(cam, objs, mats, seed, x0, y0, x1, y1, nthreads=1, count
                                                bvh["pad_eps"], bvh["pad_floor"], seed, x0, y0, x1, y1, _ptr(rgb),
                                                _ptr(rgba), cp, nthreads)
         set_tile_entries(None)
+        L.orc_set_walk_starts(None, None, 0, 0)
     assert rc == 0, rc
     return (rgb, rgba, ctr.as_dict()) if counters else (rgb, rgba)
 

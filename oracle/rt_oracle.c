@@ -610,6 +610,21 @@ static const uint32_t* g_tile_entries = NULL;
 static uint32_t g_tile_entries_gtx = 0;
 static __thread uint32_t g_entry_ref = ORC_FROM_ROOT;
 void orc_set_tile_entries(const uint32_t* entries, uint32_t gtx) { g_tile_entries = entries; g_tile_entries_gtx = gtx; }
+/* Walk starts of scattered rays (build-side, round 6; the product's rtmi_tuning::walk_start on HBM-resident trees): per sphere slot
+ * one record of 16 words {reference the walk of a ray scattered off that sphere starts at, n, indices of the n way records pre-
+ * loaded on its stack} -- way records are nodes behind the tree's own in the node array (csrc/rtmi_host.cpp, build_walk_starts).
+ * The oracle only FOLLOWS the table (any start is exact as long as every subtree hanging off the path above it is tested). */
+static const uint32_t* g_walk_starts = NULL;
+static uint32_t* g_obj_slot = NULL;
+void orc_set_walk_starts(const uint32_t* records, const uint32_t* slots, uint32_t n_slots, uint32_t n_objs) {
+    free(g_obj_slot);
+    g_obj_slot = NULL;
+    g_walk_starts = records;
+    if (!records) return;
+    g_obj_slot = (uint32_t*)malloc(((size_t)n_objs + 1u) * sizeof(uint32_t));
+    memset(g_obj_slot, 0xff, ((size_t)n_objs + 1u) * sizeof(uint32_t));
+    for (uint32_t q = 0; q < n_slots; ++q) if (slots[q] < n_objs) g_obj_slot[slots[q]] = q;
+}
 static int path_to_slot(const scene_t* sc, uint32_t ref, uint32_t slot, uint32_t* path, int depth) {
     if (ref & 0x80000000u) {
         const uint32_t first = ref & 0x00ffffffu, count = (ref >> 24) & 0x7fu;
@@ -675,6 +690,14 @@ static int bvh_intersects(const scene_t* sc, const ray_t* r, float tmin, hit_rec
     }
     if (g_entry_ref != ORC_FROM_ROOT && !no_walk) { /* a camera ray of a tile with an entry: start there (or nowhere) */
         if (g_entry_ref == 0xffffffffu) no_walk = 1; else cur = g_entry_ref;
+    }
+    if (g_walk_starts && g_origin_obj != 0xffffffffu && !no_walk) { /* a scattered ray: start where its sphere's record says, way pre-loaded */
+        const uint32_t slot = g_obj_slot[g_origin_obj];
+        if (slot != 0xffffffffu) {
+            const uint32_t* rec = g_walk_starts + (size_t)slot * 16u;
+            cur = rec[0];
+            for (uint32_t i = 0; i < rec[1] && i < 14u; ++i) stack[sp++] = rec[2u + i];
+        }
     }
     /* the pad of this segment's boxes, with the far limit the peeled leaves left */
     const float pad = ray_pad(sc, r, inv, oinv, best_t);

@@ -132,6 +132,9 @@ int orc_get_pad_mode(void);
 /* camera-ray entries of the instrumented BVH walk (the product's rtmi_tile_entries_build table, rtmi_bvh_node::child format,
  * row-major over gtx tiles per row; NULL = every walk from the root).  The table must outlive the renders that use it. */
 void orc_set_tile_entries(const uint32_t* entries, uint32_t gtx);
+/* walk starts of scattered rays (the product's rtmi_scene_get_walk_starts records, 16 words per slot; NULL = from the root);
+ * `slots` / n_slots / n_objs as passed to orc_render_rect_counter_bvh.  The table must outlive the renders that use it. */
+void orc_set_walk_starts(const uint32_t* records, const uint32_t* slots, uint32_t n_slots, uint32_t n_objs);
 void orc_counter_block(uint32_t blk, uint32_t sample, uint32_t pixel, const uint32_t key[2], uint32_t out[4]);
 
 /* --- host-side setup ------------------------------------------------------ */

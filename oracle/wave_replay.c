@@ -60,6 +60,7 @@ typedef struct {
     float glo[3], gcell[3];
     uint32_t gdim[3];
     uint32_t* grid_el;
+    int reversed;
 } rp_tree;
 
 static uint32_t rp_el_of_ref(const rp_tree* T, uint32_t ref) {
@@ -140,7 +141,8 @@ static int rp_start_at(rp_tree* T, rp_lane* L, uint32_t e) {
     uint32_t chain[64];
     int m = 0;
     for (uint32_t x = e; T->el_depth[x] >= 2u; x = T->el_parent[T->el_parent[x]]) chain[m++] = rp_way(T, x);
-    for (int i = m - 1; i >= 0; --i) L->stack[L->sp++] = chain[i]; /* the top of the tree at the bottom of the stack */
+    if (T->reversed) { for (int i = 0; i < m; ++i) L->stack[L->sp++] = chain[i]; } /* (the order a pointer chase from the leaf up would push in) */
+    else for (int i = m - 1; i >= 0; --i) L->stack[L->sp++] = chain[i]; /* the top of the tree at the bottom of the stack */
     return m;
 }
 
@@ -276,6 +278,7 @@ int orc_wave_replay(const orc_camera* cam, const orc_object* objs, uint32_t n_ob
     sc.pad_refine = pad_refine_pays(pad_classes, n_classes, pad_eps);
     rp_tree T;
     rp_build_tree(&T, &sc);
+    T.reversed = (variant & 32u) != 0u;
     memset(out, 0, RO_N * sizeof(uint64_t));
     const uint32_t W = cam->img_width, H = cam->img_height, spp = cam->samples_per_pixel;
     const uint32_t tiles_x = (W + 7u) / 8u, tiles_y = (H + 7u) / 8u, n_tiles_all = tiles_x * tiles_y;
@@ -341,7 +344,8 @@ int orc_wave_replay(const orc_camera* cam, const orc_object* objs, uint32_t n_ob
             lo[i] = fminf(r->ctr[0][i] - r->half[0][i], r->ctr[1][i] - r->half[1][i]);
             hi[i] = fmaxf(r->ctr[0][i] + r->half[0][i], r->ctr[1][i] + r->half[1][i]);
         }
-        T.gdim[0] = 64; T.gdim[1] = 4; T.gdim[2] = 64;
+        static const uint32_t dims[4][3] = {{64, 4, 64}, {32, 2, 32}, {16, 1, 16}, {32, 1, 32}};
+        for (int i = 0; i < 3; ++i) T.gdim[i] = dims[(variant >> 8) & 3u][i];
         for (int i = 0; i < 3; ++i) { T.glo[i] = lo[i]; T.gcell[i] = (hi[i] - lo[i]) / (float)T.gdim[i]; if (!(T.gcell[i] > 0)) T.gcell[i] = 1.0f; }
         const uint32_t nc = T.gdim[0] * T.gdim[1] * T.gdim[2];
         T.grid_el = malloc(nc * 4u);

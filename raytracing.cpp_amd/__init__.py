@@ -140,9 +140,10 @@ assert OBJECT_DTYPE.itemsize == 24 and MATERIAL_DTYPE.itemsize == 20 and BVH_NOD
 # every symbol include/rtmi.h declares
 EXPORTS = ("rtmi_camera_setup", "rtmi_make_world_spheres", "rtmi_scene_create", "rtmi_scene_destroy",
            "rtmi_render_rows", "rtmi_render_row_blocks_device", "rtmi_render_rect", "rtmi_render_rect_device",
+           "rtmi_render_block_list_device", "rtmi_shard_plan", "rtmi_scene_get_tile_costs",
            "rtmi_last_error", "rtmi_version",
            "rtmi_scene_get_stats", "rtmi_scene_get_accel", "rtmi_scene_get_launch_info", "rtmi_scene_get_bvh", "rtmi_scene_last_kernel_ms",
-           "rtmi_bvh_build", "rtmi_bvh_build_passes", "rtmi_tile_entries_build", "rtmi_scene_get_tile_entries", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
+           "rtmi_bvh_build", "rtmi_bvh_build_passes", "rtmi_tile_entries_build", "rtmi_scene_get_tile_entries", "rtmi_scene_get_walk_starts", "rtmi_walk_starts_build", "rtmi_frame_create", "rtmi_frame_destroy", "rtmi_frame_render",
            "rtmi_frame_render_device", "rtmi_frame_get_timing", "rtmi_frame_rccl_ranks", "rtmi_frame_get_scene")
 
 _lib = None
@@ -192,6 +193,11 @@ def lib():
     if hasattr(L, "rtmi_tile_entries_build"):  # (absent from older builds that tools/ A/B against the current one)
         L.rtmi_tile_entries_build.argtypes = [C.POINTER(Camera), vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p]
         L.rtmi_scene_get_tile_entries.argtypes = [vp, vp, u32p]
+        L.rtmi_scene_get_walk_starts.argtypes = [vp, vp, u32p]
+        L.rtmi_walk_starts_build.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p, u32p, vp]
+        L.rtmi_render_block_list_device.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint64, vp, vp, vp]
+        L.rtmi_shard_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+        L.rtmi_scene_get_tile_costs.argtypes = [vp, vp, u32p]
     L.rtmi_frame_create.argtypes = [C.POINTER(Camera), vp, C.c_uint32, vp, C.c_uint32, C.POINTER(SceneOptions),
                                     C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.rtmi_frame_destroy.argtypes = [vp]
@@ -346,6 +352,25 @@ class Scene:
                                                    C.c_void_p(d_rgb or None), C.c_void_p(d_rgba or None),
                                                    C.c_void_p(stream or None)))
 
+    def render_block_list_device(self, block_rows, blocks, seed, d_rgb=0, d_rgba=0, stream=0):
+        """rtmi_render_block_list_device: image rows [b * block_rows, + block_rows) for b in `blocks`, into a dense slice in list
+        order; raw device pointers (ints), asynchronous on `stream`."""
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint32)
+        _check(lib().rtmi_render_block_list_device(self._h, block_rows, _ptr(blocks), len(blocks), seed, C.c_void_p(d_rgb or None),
+                                                   C.c_void_p(d_rgba or None), C.c_void_p(stream or None)))
+
+    def tile_costs(self):
+        """rtmi_scene_get_tile_costs: ray segments per 8x8 tile of the image from the scene's probe, shape (tiles_y, tiles_x), or
+        None when the scene made no probe."""
+        n = C.c_uint32(0)
+        _check(lib().rtmi_scene_get_tile_costs(self._h, None, C.byref(n)))
+        if not n.value:
+            return None
+        out = np.zeros(((self.height + 7) // 8, (self.width + 7) // 8), np.uint32)
+        assert out.size == n.value
+        _check(lib().rtmi_scene_get_tile_costs(self._h, _ptr(out), C.byref(n)))
+        return out
+
     def stats(self, reset=False):
         st = Stats()
         _check(lib().rtmi_scene_get_stats(self._h, C.byref(st), int(reset)))
@@ -373,7 +398,20 @@ class Scene:
                 entries = np.zeros(((self.height + 7) // 8, (self.width + 7) // 8), np.uint32)
                 assert entries.size == nt.value
                 _check(lib().rtmi_scene_get_tile_entries(self._h, _ptr(entries), C.byref(nt)))
-        return dict(nodes=nodes, slots=slots, pad_classes=pc, pad_eps=eps.value, pad_floor=floor.value, entries=entries)
+        starts = None  # walk starts of scattered rays (rtmi_tuning::walk_start): 16 words per slot; way records sit behind the tree's nodes
+        if hasattr(lib(), "rtmi_scene_get_walk_starts"):
+            nsl = C.c_uint32(0)
+            _check(lib().rtmi_scene_get_walk_starts(self._h, None, C.byref(nsl)))
+            if nsl.value:
+                starts = np.zeros((nsl.value, 16), np.uint32)
+                _check(lib().rtmi_scene_get_walk_starts(self._h, _ptr(starts), C.byref(nsl)))
+        n_tree = len(nodes)  # (way records sit behind the tree's own nodes, numbered without a gap)
+        if starts is not None:
+            ways = starts[:, 2:][np.arange(14)[None, :] < starts[:, 1:2]]
+            if ways.size:
+                n_tree = int(ways.min())
+        return dict(nodes=nodes, slots=slots, pad_classes=pc, pad_eps=eps.value, pad_floor=floor.value, entries=entries,
+                    walk_starts=starts, n_tree_nodes=n_tree)
 
 
 class Frame:
@@ -381,13 +419,13 @@ class Frame:
     interleaved row-block shards, one RCCL gather to devices[0]."""
 
     def __init__(self, cam, objs, mats, devices=(0,), block_rows=8, accel=ACCEL_AUTO, leaf_size=0, tuning=None,
-                 rehearsal=False, force_rccl=False):
+                 rehearsal=False, force_rccl=False, cost_plan=False):
         objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
         mats = np.ascontiguousarray(mats, dtype=MATERIAL_DTYPE)
         opt, _tun = _options(accel, leaf_size, -1, False, tuning)
         # RTMI_FRAME_REHEARSAL (1): repeated devices, copies instead of RCCL; RTMI_FRAME_FORCE_RCCL (2): a communicator and
-        # the grouped gather even for one device
-        opt.reserved[0] = (1 if rehearsal else 0) | (2 if force_rccl else 0)
+        # the grouped gather even for one device; RTMI_FRAME_COST_PLAN (4): row blocks dealt out by the scene's cost map
+        opt.reserved[0] = (1 if rehearsal else 0) | (2 if force_rccl else 0) | (4 if cost_plan else 0)
         devs = (C.c_int32 * len(devices))(*devices)
         self._h = C.c_void_p()
         self.width, self.height, self.n_devices = cam.img_width, cam.img_height, len(devices)
@@ -445,6 +483,18 @@ def bvh_build(objs, leaf_size=0, bvh_passes=0):
                                        C.byref(root), C.byref(depth), _ptr(pc), C.byref(nc), C.byref(eps), C.byref(floor)))
     return dict(nodes=nodes[:nn.value].copy(), slots=slots[:n].copy(), pad_classes=pc[:nc.value].copy(),
                 pad_eps=eps.value, pad_floor=floor.value, root_ref=root.value, depth=depth.value)
+
+
+def walk_starts_build(objs, leaf_size=0, bvh_passes=0):
+    """rtmi_walk_starts_build (no device needed): (nodes, n_tree_nodes, records) -- the tree of bvh_build for the same arguments with
+    the way records behind its nodes, and the (n_objects, 16) start records of scattered rays."""
+    objs = np.ascontiguousarray(objs, dtype=OBJECT_DTYPE)
+    n = len(objs)
+    nodes = np.zeros(3 * n + 2, BVH_NODE_DTYPE)
+    rec = np.zeros((max(n, 1), 16), np.uint32)
+    nn, nt = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().rtmi_walk_starts_build(_ptr(objs), n, leaf_size, bvh_passes, _ptr(nodes), C.byref(nn), C.byref(nt), _ptr(rec)))
+    return nodes[:nn.value].copy(), nt.value, rec[:n].copy()
 
 
 def tile_entries_build(cam, objs, leaf_size=0, bvh_passes=0):
@@ -509,6 +559,50 @@ class RowShardPlan:
     def shard(self, rank):
         """(y_first, n_blocks, rows) of `rank`; block stride is world_size."""
         return self.shards[rank]
+
+
+def block_costs(tile_costs, height, block_rows):
+    """Cost of every block of `block_rows` rows from a per-8x8-tile cost map (Scene.tile_costs): a tile row counts for the block
+    its first row lies in (blocks of a multiple of 8 rows, the multi-GPU shards, are whole tile rows)."""
+    nb = (height + block_rows - 1) // block_rows
+    out = np.zeros(nb, np.uint64)
+    rows = tile_costs.astype(np.uint64).sum(axis=1)
+    for ty, c in enumerate(rows):
+        out[min(nb - 1, (ty * 8) // block_rows)] += c
+    return out
+
+
+class CostShardPlan:
+    """Row blocks of an image -> ranks by cost (rtmi_shard_plan): block b -> rank b mod N ignores that the rows of a
+    frame differ in cost -- on the 1080p S-RTOW frame the eighth-frame shards of 8 GPUs were 4 % apart -- so the blocks are dealt
+    out longest processing time first, every rank the same number of them.  Same interface as RowShardPlan (`max_rows`, `index`),
+    with `blocks(rank)` the list for rtmi_render_block_list_device.  `block_cost=None` reproduces block b -> rank b mod N.
+    The frame is bit-identical for any assignment (the draw streams are keyed by the absolute pixel)."""
+
+    def __init__(self, height, block_rows, world_size, block_cost=None):
+        self.height, self.block_rows, self.world_size = height, block_rows, world_size
+        nb = (height + block_rows - 1) // block_rows
+        self.rank_of_block = np.zeros(max(nb, 1), np.uint32)
+        cost = None if block_cost is None else np.ascontiguousarray(block_cost, dtype=np.uint64)
+        assert cost is None or len(cost) == nb
+        _check(lib().rtmi_shard_plan(height, block_rows, world_size, _ptr(cost), _ptr(self.rank_of_block)))
+        self.rank_of_block = self.rank_of_block[:nb]
+        self._blocks = [np.flatnonzero(self.rank_of_block == r).astype(np.uint32) for r in range(world_size)]  # (ascending: a clipped last block stays last)
+        rows = [int(sum(min(block_rows, height - int(b) * block_rows) for b in bl)) for bl in self._blocks]
+        self.shards = [(bl, len(bl), rw) for bl, rw in zip(self._blocks, rows)]
+        self.max_rows = max(rows) if rows else 0
+        self.index = np.zeros(height, np.int64)
+        for r, bl in enumerate(self._blocks):
+            for k, b in enumerate(bl):
+                y0 = int(b) * block_rows
+                n = min(block_rows, height - y0)
+                self.index[y0:y0 + n] = r * self.max_rows + k * block_rows + np.arange(n)
+
+    def blocks(self, rank):
+        return self._blocks[rank]
+
+    def rows(self, rank):
+        return self.shards[rank][2]
 
 
 def gather_frame(local_slice, plan, rank, dst=0, group=None):

@@ -130,6 +130,9 @@ struct rtmi_scene {
     uint4* d_aux = nullptr;
     uint4* d_mats = nullptr;
     uint4* d_nodes = nullptr;
+    uint4* d_walk_starts = nullptr;   // scattered rays of HBM-resident trees: per slot the start record of build_walk_starts (NULL: the root)
+    std::vector<uint32_t> walk_starts; // (host copy for rtmi_scene_get_walk_starts: the tests' instrumented CPU walk)
+    uint32_t n_tree_nodes = 0;         // nodes of the tree itself; bvh.nodes may hold way records behind them
     uint32_t* d_tile_entry = nullptr; // camera-ray entry per 8x8 tile of the image (build_tile_entries), NULL: walks start at the root
     std::vector<uint32_t> tile_entries; // the same table in the builder's reference format (rtmi_scene_get_tile_entries: the tests' instrumented CPU walk)
     float entry_build_ms = 0.0f;
@@ -162,9 +165,12 @@ struct rtmi_scene {
     int cost_state = 0;             // 0: no probe yet, 1: tile_cost valid, -1: the probe failed (row-by-row order from then on)
     std::vector<uint32_t> tile_cost;
     float probe_ms = 0.0f;
-    struct OrderEntry {
-        uint32_t key[6]; // y_first, block_rows, block_stride, n_blocks, x0, x1
-        uint32_t* d_order;
+    double probe_seg_per_sample = 1.0; // ray segments per sample over the probe's frame
+    struct OrderEntry { // what a launch geometry needs on the device: the order of its tiles and, for a list of row blocks, their first rows
+        uint32_t key[8]; // y_first, block_rows, block_stride, n_blocks, x0, x1, hash of the block list (two words; 0 for a strided set)
+        uint32_t* d_order;       // NULL: no cost map, tiles row by row
+        uint32_t* d_first_row;   // NULL: a strided set of blocks
+        std::vector<uint32_t> h_first_row;
         std::vector<uint32_t> h_order; // (kept: the upload is asynchronous on the stream of the call that made the entry)
         uint32_t n_tiles;
         double cost;     // sum over the entry's tiles
@@ -176,7 +182,7 @@ struct rtmi_scene {
     uint32_t lds_spheres = 0, lds_aux = 0, lds_mats = 0, lds_nodes = 0, lds_stack = 0;
     // lanes waiting for shading that end a traversal round (A/B on MI355X, round 2: 52 = 56 on the LDS-resident RTOW
     // scene, 3.5 % better than 56 on the HBM-resident 100k-sphere scene; 62 costs that scene 23 %)
-    uint32_t wait_thresh = 52;
+    uint32_t wait_thresh = 52; // (scene_create: 56 for trees staged into LDS since camera rays have entries, round 6: 126.6 against 127.8 ms)
 
     uint32_t lds_att = 0, lds_pool = 0;
     uint32_t lds_top_nodes = 0; // HBM-resident trees: breadth-first nodes staged into LDS (48-byte records at the start of the segment)
@@ -218,6 +224,7 @@ void free_scene(rtmi_scene* s) {
     hipFree(s->d_mats);
     hipFree(s->d_nodes);
     hipFree(s->d_tile_entry);
+    hipFree(s->d_walk_starts);
     hipFree(s->d_stats);
     hipFree(s->d_tail);
     hipFree(s->d_rgb);
@@ -228,7 +235,7 @@ void free_scene(rtmi_scene* s) {
         hipFree(sl.d_samples);
         hipFree(sl.d_chain);
     }
-    for (auto& e : s->orders) hipFree(e->d_order);
+    for (auto& e : s->orders) { hipFree(e->d_order); hipFree(e->d_first_row); }
     for (hipEvent_t e : s->ev_trace) hipEventDestroy(e);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
@@ -243,11 +250,12 @@ void fill_scene_params(const rtmi_scene* s, RtmiLaunch& P) {
     P.nodes = s->d_nodes;
     P.n_slots = s->n_objects;
     P.n_mats = s->n_mats;
-    P.n_nodes = (uint32_t)s->bvh.nodes.size();
+    P.n_nodes = s->n_tree_nodes;
     P.root_ref = s->root_ref_dev;
     std::memcpy(P.pre_leaf, s->pre_leaf_dev, sizeof(P.pre_leaf));
     P.n_pre_leaves = s->n_pre_leaves;
     P.tile_entry = s->d_tile_entry;
+    P.walk_starts = s->d_walk_starts;
     std::memcpy(P.pad_classes, s->bvh.pad_classes, sizeof(P.pad_classes));
     P.n_pad_classes = s->bvh.n_pad_classes;
     P.pad_eps = s->bvh.pad_eps;
@@ -272,7 +280,8 @@ void fill_scene_params(const rtmi_scene* s, RtmiLaunch& P) {
 }
 
 // rows a set of row blocks covers, validated: every block must start inside the image; only the last one may be clipped
-int count_rows(const rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks, uint32_t& n_local_rows) {
+int count_rows(const rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks, uint32_t& n_local_rows,
+               const uint32_t* block_list = nullptr) {
     const uint32_t H = s->cam.img_height;
     if (block_rows == 0 || block_stride == 0) {
         set_error("rtmi: block_rows and block_stride must be positive");
@@ -280,7 +289,7 @@ int count_rows(const rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint3
     }
     n_local_rows = 0;
     for (uint32_t k = 0; k < n_blocks; ++k) {
-        const uint64_t y = (uint64_t)y_first + (uint64_t)k * block_stride * block_rows;
+        const uint64_t y = block_list ? (uint64_t)block_list[k] * block_rows : (uint64_t)y_first + (uint64_t)k * block_stride * block_rows;
         if (y >= H) {
             set_error("rtmi: row block starts outside the image");
             return RTMI_ERR_BAD_ARG;
@@ -352,9 +361,12 @@ void probe_tile_costs(rtmi_scene* s, hipStream_t stream) {
               hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(s->grid), dim3(s->block), args, s->lds_bytes, stream) == hipSuccess &&
               hipEventRecord(e1, stream) == hipSuccess;
     std::vector<uint32_t> cost(n);
+    unsigned long long pst[2] = {0ull, 0ull}; // {samples, segments} of the probe
     ok = ok && hipMemcpyAsync(cost.data(), d_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+         hipMemcpyAsync(pst, d_pstats, sizeof(pst), hipMemcpyDeviceToHost, stream) == hipSuccess &&
          hipStreamSynchronize(stream) == hipSuccess;
     if (ok) {
+        s->probe_seg_per_sample = pst[0] ? (double)pst[1] / (double)pst[0] : 1.0;
         (void)hipEventElapsedTime(&s->probe_ms, e0, e1);
         s->tile_cost.swap(cost);
         s->cost_state = 1;
@@ -362,46 +374,74 @@ void probe_tile_costs(rtmi_scene* s, hipStream_t stream) {
     cleanup();
 }
 
-// Hand-out order of the 8x8 tiles of one launch, costliest first (longest processing time first: what is left for the end of
-// the launch are the cheapest items it has).  A local tile takes the cost of the image tile its first pixel lies in (row blocks
-// of 8 rows starting at a multiple of 8 -- the multi-GPU shards -- coincide with image tiles).  Cached per geometry.
+// first image row of local block k of a launch: a strided set (y_first + k * block_stride * block_rows) or a list of block indices
+inline uint32_t block_row(uint32_t k, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, const uint32_t* block_list) {
+    return block_list ? block_list[k] * block_rows : y_first + k * block_stride * block_rows;
+}
+
+// What a launch geometry needs on the device, cached per geometry: the hand-out order of its 8x8 tiles, costliest first (longest
+// processing time first: what is left for the end of the launch are the cheapest items it has; a local tile takes the cost of the
+// image tile its first pixel lies in -- row blocks of 8 rows starting at a multiple of 8, the multi-GPU shards, coincide with image
+// tiles), and for a launch over a LIST of row blocks the first row of each.  Both tables are uploaded on the stream of the call
+// that makes the entry, in front of its kernel; the host copies live as long as the entry.  NULL: nothing to hand to the kernel.
 const rtmi_scene::OrderEntry* order_for(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks,
-                                        uint32_t n_local_rows, uint32_t x0, uint32_t x1, hipStream_t stream) {
-    if (s->cost_state != 1) return nullptr;
-    const uint32_t key[6] = {y_first, block_rows, block_stride, n_blocks, x0, x1};
+                                        const uint32_t* block_list, uint32_t n_local_rows, uint32_t x0, uint32_t x1, bool want_order,
+                                        hipStream_t stream) {
+    const bool ordered = want_order && s->cost_state == 1;
+    if (!ordered && !block_list) return nullptr;
+    uint64_t h = 0;
+    if (block_list) {
+        h = 0xcbf29ce484222325ull; // FNV-1a over the list
+        for (uint32_t k = 0; k < n_blocks; ++k) h = (h ^ block_list[k]) * 0x100000001b3ull;
+        h |= 1ull;
+    }
+    const uint32_t key[8] = {block_list ? 0u : y_first, block_rows, block_list ? 0u : block_stride, n_blocks, x0, x1, (uint32_t)h, (uint32_t)(h >> 32)};
     for (const auto& e : s->orders)
-        if (std::memcmp(e->key, key, sizeof(key)) == 0) return e.get();
+        if (std::memcmp(e->key, key, sizeof(key)) == 0 && (e->d_order != nullptr) == ordered &&
+            (!block_list || (e->h_first_row.size() == n_blocks && [&] { for (uint32_t k = 0; k < n_blocks; ++k) if (e->h_first_row[k] != block_list[k] * block_rows) return false; return true; }())))
+            return e.get();
     const uint32_t W = s->cam.img_width;
     const uint32_t gtx = (W + 7u) / 8u;
     const uint32_t tiles_x = (x1 - x0 + 7u) / 8u, tiles_y = (n_local_rows + 7u) / 8u;
     const size_t n = (size_t)tiles_x * tiles_y;
-    std::vector<uint64_t> keyed(n); // cost << 32 | (0xffffffff - tile): descending sort = costliest first, ties in tile order
-    double total = 0.0;
-    for (uint32_t ty = 0; ty < tiles_y; ++ty) {
-        const uint32_t ply = ty * 8u, blk = ply / block_rows;
-        const uint32_t gy = y_first + blk * block_stride * block_rows + (ply - blk * block_rows);
-        for (uint32_t tx = 0; tx < tiles_x; ++tx) {
-            const size_t g = (size_t)(gy >> 3) * gtx + ((x0 + tx * 8u) >> 3);
-            const uint32_t c = g < s->tile_cost.size() ? s->tile_cost[g] : 0u;
-            const uint32_t tile = ty * tiles_x + tx;
-            keyed[tile] = ((uint64_t)c << 32) | (0xffffffffu - tile);
-            total += c;
-        }
-    }
-    std::sort(keyed.begin(), keyed.end(), std::greater<uint64_t>());
     auto e = std::make_unique<rtmi_scene::OrderEntry>();
-    e->h_order.resize(n);
-    for (size_t i = 0; i < n; ++i) e->h_order[i] = 0xffffffffu - (uint32_t)keyed[i];
     std::memcpy(e->key, key, sizeof(key));
     e->n_tiles = (uint32_t)n;
-    e->cost = total;
+    e->cost = 0.0;
     e->d_order = nullptr;
-    // (stream-ordered in front of the kernel that reads it; the host copy lives as long as the entry)
-    if (hipMalloc(reinterpret_cast<void**>(&e->d_order), std::max<size_t>(n, 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMemcpyAsync(e->d_order, e->h_order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream) != hipSuccess) {
+    e->d_first_row = nullptr;
+    auto fail = [&]() -> const rtmi_scene::OrderEntry* {
         hipFree(e->d_order);
+        hipFree(e->d_first_row);
         (void)hipGetLastError();
         return nullptr;
+    };
+    if (ordered) {
+        std::vector<uint64_t> keyed(n); // cost << 32 | (0xffffffff - tile): descending sort = costliest first, ties in tile order
+        for (uint32_t ty = 0; ty < tiles_y; ++ty) {
+            const uint32_t ply = ty * 8u, blk = ply / block_rows;
+            const uint32_t gy = block_row(blk, y_first, block_rows, block_stride, block_list) + (ply - blk * block_rows);
+            for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+                const size_t g = (size_t)(gy >> 3) * gtx + ((x0 + tx * 8u) >> 3);
+                const uint32_t c = g < s->tile_cost.size() ? s->tile_cost[g] : 0u;
+                const uint32_t tile = ty * tiles_x + tx;
+                keyed[tile] = ((uint64_t)c << 32) | (0xffffffffu - tile);
+                e->cost += c;
+            }
+        }
+        std::sort(keyed.begin(), keyed.end(), std::greater<uint64_t>());
+        e->h_order.resize(n);
+        for (size_t i = 0; i < n; ++i) e->h_order[i] = 0xffffffffu - (uint32_t)keyed[i];
+        if (hipMalloc(reinterpret_cast<void**>(&e->d_order), std::max<size_t>(n, 1) * sizeof(uint32_t)) != hipSuccess ||
+            hipMemcpyAsync(e->d_order, e->h_order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream) != hipSuccess)
+            return fail();
+    }
+    if (block_list) {
+        e->h_first_row.resize(n_blocks);
+        for (uint32_t k = 0; k < n_blocks; ++k) e->h_first_row[k] = block_list[k] * block_rows;
+        if (hipMalloc(reinterpret_cast<void**>(&e->d_first_row), std::max<size_t>(n_blocks, 1) * sizeof(uint32_t)) != hipSuccess ||
+            hipMemcpyAsync(e->d_first_row, e->h_first_row.data(), n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, stream) != hipSuccess)
+            return fail();
     }
     s->orders.push_back(std::move(e));
     return s->orders.back().get();
@@ -409,13 +449,13 @@ const rtmi_scene::OrderEntry* order_for(rtmi_scene* s, uint32_t y_first, uint32_
 
 // one launch sequence (trace + resolve) over columns [x0, x1) of a set of row blocks; `band`: position within the call (every
 // band's trace kernel sits between its own pair of events)
-int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks,
+int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks, const uint32_t* block_list,
                uint32_t x0, uint32_t x1, uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream, uint32_t band,
                const rtmi_scene::OrderEntry* order, size_t per_slot_cap) {
     LaunchSlot& sl = s->slot[0];
     const uint32_t W = s->cam.img_width;
     uint32_t n_local_rows = 0;
-    const int rc_rows = count_rows(s, y_first, block_rows, block_stride, n_blocks, n_local_rows);
+    const int rc_rows = count_rows(s, y_first, block_rows, block_stride, n_blocks, n_local_rows, block_list);
     if (rc_rows != RTMI_OK) return rc_rows;
     if (n_local_rows == 0 || x1 <= x0) return RTMI_OK;
     const uint32_t Wl = x1 - x0;
@@ -447,7 +487,12 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
     // short next to the launch: ~128 work items per lane of the persistent grid, never below 4 samples (round 4: the eighth of
     // the frame one of 8 GPUs renders, trace-kernel ms for chunks of 2 / 3 / 4 / 5 / 6 / 8: 19.26 / 18.30 / 17.90 / 17.96 /
     // 18.29 / 18.82; whole frame 4: 223.1, 8: 219.1, 16: 217.8, 24: 217.6, 32: 219.0, 86: 235.4 on the round-2 kernel).
-    const rtmi_scene::OrderEntry* ord = (order && order->n_tiles == P.tiles_x * P.tiles_y) ? order : nullptr;
+    if (block_list && (!order || !order->d_first_row)) {
+        set_error("rtmi: the table of a block-list launch could not be allocated");
+        return RTMI_ERR_OOM;
+    }
+    P.block_first_row = block_list ? order->d_first_row : nullptr;
+    const rtmi_scene::OrderEntry* ord = (order && order->d_order && order->n_tiles == P.tiles_x * P.tiles_y) ? order : nullptr;
     P.tile_order = ord ? ord->d_order : nullptr;
     // (with the costliest tiles first the heavy items start when the launch does and it ends in the cheapest ones: items can be
     // longer -- ~24 per lane, at most 32 samples; tools/sched_ab.py, trace + resolve ms without / with the order at the best chunk
@@ -462,7 +507,7 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
         if (ord) {
             // ... and no longer than ~130 ray segments (the probe's mean per sample: 4 on S-RTOW, 79 in the box of config 5,
             // where 32 samples would be 2 500 rounds -- 20 ms -- of a lane: 848 ms against 840 with chunks of 4-16 at 1024 spp)
-            const double seg_per_sample = ord->cost / std::max(1.0, (double)ord->n_tiles * 64.0 * std::min<uint32_t>(2u, spp));
+            const double seg_per_sample = s->probe_seg_per_sample; // (the frame's mean: the cost map itself is in time units since round 6)
             const uint32_t by_cost = (uint32_t)std::max(4.0, std::min(32.0, 130.0 / std::max(1.0, seg_per_sample)));
             chunk = std::min(chunk, by_cost);
         }
@@ -579,20 +624,24 @@ int launch_one(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t bl
 // sequence each, one after the other (config 5: 800 x 800 x 4096 spp = 251 GB of records and chain slots: three bands under
 // the 96 GB cap of a 288 GB device).  The draw streams are keyed by the absolute pixel: banding does not change a bit of the image.
 int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_stride, uint32_t n_blocks, uint32_t x0, uint32_t x1,
-           uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream) {
+           uint64_t seed, float* d_rgb, uint32_t* d_rgba, hipStream_t stream, const uint32_t* block_list = nullptr) {
     const uint32_t H = s->cam.img_height, W = s->cam.img_width, spp = s->cam.samples_per_pixel;
     if (x0 > x1 || x1 > W) {
         set_error("rtmi: columns outside the image");
         return RTMI_ERR_BAD_ARG;
     }
+    if (block_list && (block_rows == 0u || (block_rows & 7u) != 0u)) {
+        set_error("rtmi: a list of row blocks needs block_rows to be a multiple of 8 (the kernel's tiles must not straddle blocks)");
+        return RTMI_ERR_BAD_ARG;
+    }
     uint32_t rows_total = 0;
-    const int rc_rows = count_rows(s, y_first, block_rows, block_stride, n_blocks, rows_total);
+    const int rc_rows = count_rows(s, y_first, block_rows, block_stride, n_blocks, rows_total, block_list);
     if (rc_rows != RTMI_OK) return rc_rows;
     if (rows_total == 0 || x1 == x0) return RTMI_OK;
     const uint32_t Wl = x1 - x0;
 
     // a band is a run of units: 8 rows of a contiguous call (tile rows stay whole), or one row block of a sharded call
-    const bool contiguous = n_blocks == 1;
+    const bool contiguous = n_blocks == 1 && !block_list;
     const uint32_t rows_c = contiguous ? std::min(block_rows, H - y_first) : 0u;
     const uint64_t sample_bytes = sizeof(float4) + (s->packed_ok ? (size_t)s->att_words * 4u : 0u);
     const uint64_t row_bytes = (uint64_t)Wl * spp * sample_bytes;
@@ -601,6 +650,7 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
         size_t row0;                            // first row of the band in the call's dense output
         uint32_t rows;
         const rtmi_scene::OrderEntry* order;
+        const uint32_t* list;                   // the band's part of the call's block list (NULL: strided)
     };
     std::vector<Band> bands;
     uint32_t n_bands = 1;
@@ -643,12 +693,13 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
             Band& b = bands[k];
             if (contiguous) {
                 const uint32_t r0 = u0 * unit_rows, nr = std::min(nu * unit_rows, rows_c - r0);
-                b = Band{y_first + r0, nr, 1u, (size_t)r0, nr, nullptr};
+                b = Band{y_first + r0, nr, 1u, (size_t)r0, nr, nullptr, nullptr};
             } else {
                 uint32_t rows = 0;
-                const int rc = count_rows(s, y_first + u0 * block_stride * block_rows, block_rows, block_stride, nu, rows);
+                const uint32_t* sub = block_list ? block_list + u0 : nullptr;
+                const int rc = count_rows(s, y_first + u0 * block_stride * block_rows, block_rows, block_stride, nu, rows, sub);
                 if (rc != RTMI_OK) return rc;
-                b = Band{y_first + u0 * block_stride * block_rows, block_rows, nu, (size_t)u0 * block_rows, rows, nullptr};
+                b = Band{y_first + u0 * block_stride * block_rows, block_rows, nu, (size_t)u0 * block_rows, rows, nullptr, sub};
             }
             max_band_rows = std::max(max_band_rows, b.rows);
         }
@@ -682,14 +733,15 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     const uint64_t tiles_total = (uint64_t)((Wl + 7u) / 8u) * ((rows_total + 7u) / 8u);
     const bool want_order = s->tile_order_mode == 2u || (s->tile_order_mode == 0u && !s->big && tiles_total >= 2048u && spp >= 16u);
     s->last_tile_order = 0;
-    if (want_order && n_bands <= 256u) {
+    if ((want_order && n_bands <= 256u) || block_list) {
         if (s->orders.size() + n_bands > 512u) { // (a host that walks through many geometries: start over rather than grow)
             HIP_TRY(hipDeviceSynchronize());
-            for (auto& e : s->orders) hipFree(e->d_order);
+            for (auto& e : s->orders) { hipFree(e->d_order); hipFree(e->d_first_row); }
             s->orders.clear();
         }
-        for (Band& b : bands) b.order = order_for(s, b.y_first, b.block_rows, block_stride, b.n_blocks, b.rows, x0, x1, stream);
-        s->last_tile_order = (s->cost_state == 1 && bands[0].order) ? 1u : 0u;
+        for (Band& b : bands)
+            b.order = order_for(s, b.y_first, b.block_rows, block_stride, b.n_blocks, b.list, b.rows, x0, x1, want_order && n_bands <= 256u, stream);
+        s->last_tile_order = (s->cost_state == 1 && bands[0].order && bands[0].order->d_order) ? 1u : 0u;
     }
     s->last_bands = n_bands;
     s->n_bands_timed = 0;
@@ -698,7 +750,7 @@ int launch(rtmi_scene* s, uint32_t y_first, uint32_t block_rows, uint32_t block_
     auto out_rgba = [&](const Band& b) { return d_rgba ? d_rgba + b.row0 * Wl : nullptr; };
     for (uint32_t k = 0; k < n_bands; ++k) {
         const Band& b = bands[k];
-        const int rc = launch_one(s, b.y_first, b.block_rows, block_stride, b.n_blocks, x0, x1, seed, out_rgb(b), out_rgba(b), stream, k, b.order, cap);
+        const int rc = launch_one(s, b.y_first, b.block_rows, block_stride, b.n_blocks, b.list, x0, x1, seed, out_rgb(b), out_rgba(b), stream, k, b.order, cap);
         if (rc != RTMI_OK) return rc;
         s->n_bands_timed = k + 1u;
     }
@@ -797,6 +849,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         for (uint32_t i = 0; i < n_objects; ++i) slot_object[i] = i;
         s->bvh.root_ref = 0;
     }
+    s->n_tree_nodes = (uint32_t)s->bvh.nodes.size();
     std::vector<uint4> h_spheres(n_objects), h_aux(n_objects), h_mats((size_t)n_materials);
     auto fbits = [](float f) {
         uint32_t u;
@@ -904,6 +957,17 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     HIP_TRY_S(upload(&s->d_aux, h_aux.data(), h_aux.size() * sizeof(uint4)));
     HIP_TRY_S(upload(&s->d_mats, h_mats.data(), h_mats.size() * sizeof(uint4)));
     {
+        // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start
+        // every walk below them
+        uint32_t walk_root = s->bvh.root_ref, pre[4] = {};
+        if (s->accel == RTMI_ACCEL_BVH && !s->bvh.nodes.empty()) walk_root = peel_top_leaves(s->bvh, pre, s->n_pre_leaves);
+        // scattered rays of trees that stay in HBM start in their own leaf (rtmi_tuning::walk_start): way records behind the nodes
+        std::vector<uint32_t> starts;
+        if (s->accel == RTMI_ACCEL_BVH && s->big && tune.walk_start != 1u && walk_root != kNoWalkRef && !(walk_root & kLeafBit) &&
+            !s->bvh.nodes.empty()) {
+            build_walk_starts(s->bvh, walk_root, starts);
+            if (s->bvh.nodes.size() == s->n_tree_nodes) starts.clear(); // (no sphere has a way: a tree of two levels)
+        }
         // device copy of the nodes: LDS-resident scenes get their references in the 16-bit stack-entry form
         std::vector<rtmi_bvh_node> dn = s->bvh.nodes;
         // (leaf references are stored sign-extended: as 32-bit integers nodes are >= 0, leaves < -1 and the stack's
@@ -912,7 +976,6 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
             return (ref & kLeafBit) ? (0xffff8000u | ((((ref >> 24) & 0x7fu) - 1u) << 13) | (ref & 0x1fffu)) : ref;
         };
         s->root_ref_dev = s->bvh.root_ref;
-        uint32_t walk_root = s->bvh.root_ref;
         if (!s->big && s->accel == RTMI_ACCEL_BVH && n_objects > 0) {
             for (auto& nd : dn) {
                 nd.child[0] = pack16(nd.child[0]);
@@ -920,12 +983,8 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
             }
             s->root_ref_dev = pack16(s->bvh.root_ref);
         }
-        // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start
-        // every walk below them
         auto dev_ref = [&](uint32_t ref) { return ref == kNoWalkRef ? kNoWalk : (s->big ? ref : pack16(ref)); };
         if (s->accel == RTMI_ACCEL_BVH && !dn.empty()) {
-            uint32_t pre[4];
-            walk_root = peel_top_leaves(s->bvh, pre, s->n_pre_leaves);
             for (uint32_t q = 0; q < s->n_pre_leaves; ++q) s->pre_leaf_dev[q] = dev_ref(pre[q]);
             if (s->n_pre_leaves) s->root_ref_dev = dev_ref(walk_root);
         }
@@ -968,6 +1027,10 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
                 r[10] = dn[i].child[1];
             }
             HIP_TRY_S(upload(&s->d_nodes, rec.data(), rec.size() * sizeof(uint32_t)));
+            if (!starts.empty()) {
+                HIP_TRY_S(upload(&s->d_walk_starts, starts.data(), starts.size() * sizeof(uint32_t)));
+                s->walk_starts.swap(starts);
+            }
             // camera rays start at their tile's entry (rtmi_tuning::cam_entry; host: build_tile_entries, csrc/rtmi_host.cpp)
             if (s->accel == RTMI_ACCEL_BVH && (tune.cam_entry == 2u || (tune.cam_entry == 0u && !s->big)) && walk_root != kNoWalkRef && !(walk_root & kLeafBit)) {
                 const auto t0 = std::chrono::steady_clock::now();
@@ -1007,6 +1070,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     hipDeviceProp_t prop;
     HIP_TRY_S(hipGetDeviceProperties(&prop, dev));
     if (tune.blocks_per_cu) per_cu = std::max(1, std::min(per_cu, (int)tune.blocks_per_cu));
+    if (!s->big && s->accel == RTMI_ACCEL_BVH && s->d_tile_entry != nullptr) s->wait_thresh = 56u;
     if (tune.wait_thresh) s->wait_thresh = std::min(64u, tune.wait_thresh);
 
     if (tune.chunk_samples) s->chunk = tune.chunk_samples < 0 ? 0u : (uint32_t)tune.chunk_samples; // 0: split off
@@ -1108,6 +1172,32 @@ extern "C" int rtmi_render_row_blocks_device(rtmi_scene* s, uint32_t y_first, ui
         return launch(s, y_first, block_rows, block_stride, n_blocks, 0u, s->cam.img_width, seed, static_cast<float*>(d_rgb_linear_out),
                       static_cast<uint32_t*>(d_rgba8_out), static_cast<hipStream_t>(hip_stream));
     });
+}
+
+extern "C" int rtmi_render_block_list_device(rtmi_scene* s, uint32_t block_rows, const uint32_t* blocks, uint32_t n_blocks, uint64_t seed,
+                                             void* d_rgb_linear_out, void* d_rgba8_out, void* hip_stream) {
+    DeviceGuard guard;
+    return guarded("rtmi_render_block_list_device", [&]() -> int {
+        if (!s || (n_blocks && !blocks)) {
+            set_error("rtmi_render_block_list_device: null argument");
+            return RTMI_ERR_BAD_ARG;
+        }
+        if (n_blocks == 0) return RTMI_OK;
+        std::lock_guard<std::mutex> lock(s->mu);
+        HIP_TRY(hipSetDevice(s->device));
+        return launch(s, 0u, block_rows, 1u, n_blocks, 0u, s->cam.img_width, seed, static_cast<float*>(d_rgb_linear_out),
+                      static_cast<uint32_t*>(d_rgba8_out), static_cast<hipStream_t>(hip_stream), blocks);
+    });
+}
+
+extern "C" int rtmi_scene_get_tile_costs(const rtmi_scene* s, uint32_t* costs_out, uint32_t* n_tiles) {
+    if (!s || !n_tiles) {
+        set_error("rtmi_scene_get_tile_costs: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    *n_tiles = s->cost_state == 1 ? (uint32_t)s->tile_cost.size() : 0u; // (0: the scene made no probe)
+    if (costs_out && *n_tiles) std::memcpy(costs_out, s->tile_cost.data(), s->tile_cost.size() * sizeof(uint32_t));
+    return RTMI_OK;
 }
 
 // pixels [x0, x1) x [y0, y1) into a dense (x1 - x0)-wide output, device pointers, asynchronous on `hip_stream`
@@ -1239,6 +1329,7 @@ extern "C" int rtmi_scene_get_launch_info(const rtmi_scene* s, rtmi_launch_info*
     v.cam_entry = s->d_tile_entry != nullptr ? 1u : 0u;
     v.entry_build_us = (uint32_t)(s->entry_build_ms * 1000.0f + 0.5f);
     v.reband_retries = s->reband_retries;
+    v.walk_start = s->d_walk_starts != nullptr ? 1u : 0u;
     std::memcpy(out, &v, std::min<size_t>(out->struct_size, sizeof(v)));
     return RTMI_OK;
 }
@@ -1262,6 +1353,16 @@ extern "C" int rtmi_scene_get_bvh(const rtmi_scene* s, rtmi_bvh_node* nodes_out,
     if (nodes_out) std::memcpy(nodes_out, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(rtmi_bvh_node));
     if (slots_out) std::memcpy(slots_out, s->bvh.slot_object.data(), s->bvh.slot_object.size() * sizeof(uint32_t));
     if (pad_classes_out) std::memcpy(pad_classes_out, s->bvh.pad_classes, s->bvh.n_pad_classes * 8 * sizeof(float));
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_get_walk_starts(const rtmi_scene* s, uint32_t* records_out, uint32_t* n_slots) {
+    if (!s || !n_slots) {
+        set_error("rtmi_scene_get_walk_starts: null argument");
+        return RTMI_ERR_BAD_ARG;
+    }
+    *n_slots = (uint32_t)(s->walk_starts.size() / 16u); // (0: every scattered ray's walk starts at the root)
+    if (records_out && !s->walk_starts.empty()) std::memcpy(records_out, s->walk_starts.data(), s->walk_starts.size() * sizeof(uint32_t));
     return RTMI_OK;
 }
 

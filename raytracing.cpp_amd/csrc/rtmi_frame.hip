@@ -2,8 +2,8 @@
 //
 // Replaces the worker fan-out of the reference's RayTracer::create (src/main.cc:586-731: one std::thread per core,
 // a shuffled queue of 8x8 tiles) and the per-frame drain of RayTracer::update (src/main.cc:733-774: ZeroMQ inproc
-// mailboxes, one message per pixel) by: one scene replica per device, the image plane sharded by interleaved row
-// blocks (block b -> device b mod n), ONE RCCL gather of the dense per-device slices (float RGB and RGBA8 of a device
+// mailboxes, one message per pixel) by: one scene replica per device, the image plane sharded by row blocks (dealt out by the
+// scene's cost map, longest processing time first; block b -> device b mod n without one), ONE RCCL gather of the dense per-device slices (float RGB and RGBA8 of a device
 // packed into one buffer, so that a frame is one ncclGather per rank) over xGMI to devices[0], and a small kernel that
 // restores scanline order.  No exchange happens during rendering: pixels are independent and the
 // draw streams are keyed by absolute (pixel, sample), so the frame is bit-identical for any n.
@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(256) rtmi_deinterleave_kernel(const uint32_t* 
 
 struct Shard {
     uint32_t y_first = 0, n_blocks = 0, rows = 0;
+    std::vector<uint32_t> blocks; // cost-balanced plan: the rank's row blocks, ascending (empty: the strided set y_first, n_blocks)
 };
 
 } // namespace
@@ -96,6 +97,7 @@ struct rtmi_frame {
     uint32_t n = 0, W = 0, H = 0, block_rows = 8, max_rows = 0;
     bool rehearsal = false; // test hook: devices may repeat, slices are gathered with copies instead of RCCL
     bool force_rccl = false; // test hook: a communicator and the gather even for n == 1 (rank 0 gathers from itself)
+    bool by_cost = false;    // the row blocks were dealt out by the scene's cost map (rtmi_shard_plan) instead of block b -> device b mod n
     size_t slice_words = 0;  // 32-bit words per slice: max_rows * W * (3 + 1)
     std::vector<int> devices;
     std::vector<rtmi_scene*> scenes;
@@ -208,20 +210,58 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
     f->d_slice.assign(n, nullptr);
     f->shards.assign(n, Shard{});
 
-    // interleaved row blocks: block b -> device b mod n; every device renders into a dense slice of max_rows rows
+    // one scene replica per device (each makes its own cost probe: the same integers on every device)
     const uint32_t H = f->H, W = f->W, B = f->block_rows;
+    for (uint32_t i = 0; i < n; ++i) {
+        HIPF(hipSetDevice(devices[i]));
+        opt.device = devices[i];
+        const int rc = rtmi_scene_create(camera, objects, n_objects, materials, n_materials, &opt, &f->scenes[i]);
+        if (rc != RTMI_OK) return rc;
+        HIPF(hipStreamCreateWithFlags(&f->streams[i], hipStreamNonBlocking));
+    }
+    // Row blocks -> devices: block b -> device b mod n, or (RTMI_FRAME_COST_PLAN) by the scene's cost map where it
+    // has one and the blocks are whole tile rows: longest processing time first, the same number to every device (rtmi_shard_plan),
+    // every device rendering its LIST of blocks into a dense slice of max_rows rows.  The frame is bit-identical for any assignment.
+    // Opt-in because it measured nothing: the eighth-frame shards of the 1080p S-RTOW frame are 4 % apart under either plan
+    // (slowest 17.88 / 17.86 ms: profiles/r06_shard_perf.txt) -- segment counts balance to 0.1 %, shard times do not follow them.
     const uint32_t n_blocks_total = (H + B - 1) / B;
+    std::vector<uint32_t> rank_of_block(std::max(1u, n_blocks_total), 0u);
+    bool by_cost = false;
+    if (n > 1 && (B & 7u) == 0u && n_blocks_total >= n && (opt.reserved[0] & RTMI_FRAME_COST_PLAN) != 0u) {
+        uint32_t n_tiles = 0;
+        if (rtmi_scene_get_tile_costs(f->scenes[0], nullptr, &n_tiles) == RTMI_OK && n_tiles != 0u) {
+            std::vector<uint32_t> tc(n_tiles);
+            std::vector<uint64_t> bc(n_blocks_total, 0u);
+            const uint32_t gtx = (W + 7u) / 8u;
+            if (rtmi_scene_get_tile_costs(f->scenes[0], tc.data(), &n_tiles) == RTMI_OK && gtx != 0u) {
+                for (uint32_t t = 0; t < n_tiles; ++t) bc[std::min(n_blocks_total - 1u, ((t / gtx) * 8u) / B)] += tc[t];
+                by_cost = rtmi_shard_plan(H, B, n, bc.data(), rank_of_block.data()) == RTMI_OK;
+            }
+        }
+    }
+    if (!by_cost) {
+        const int rc = rtmi_shard_plan(H, B, n, nullptr, rank_of_block.data());
+        if (rc != RTMI_OK) return rc;
+    }
+    f->by_cost = by_cost;
     std::vector<uint32_t> index(H, 0u);
     for (uint32_t r = 0; r < n; ++r) {
         Shard& sh = f->shards[r];
         sh.y_first = r * B;
-        sh.n_blocks = n_blocks_total > r ? (n_blocks_total - r + n - 1) / n : 0u;
-        for (uint32_t k = 0; k < sh.n_blocks; ++k) sh.rows += std::min(B, H - (r + k * n) * B);
+        for (uint32_t b = 0; b < n_blocks_total; ++b) {
+            if (rank_of_block[b] != r) continue;
+            if (by_cost) sh.blocks.push_back(b);
+            sh.n_blocks++;
+            sh.rows += std::min(B, H - b * B);
+        }
         f->max_rows = std::max(f->max_rows, sh.rows);
     }
-    for (uint32_t y = 0; y < H; ++y) {
-        const uint32_t b = y / B, r = b % n, k = b / n;
-        index[y] = r * f->max_rows + k * B + (y - b * B);
+    {
+        std::vector<uint32_t> k_of_rank(n, 0u);
+        for (uint32_t b = 0; b < n_blocks_total; ++b) {
+            const uint32_t r = rank_of_block[b], k = k_of_rank[r]++;
+            for (uint32_t y = b * B; y < std::min(H, (b + 1u) * B); ++y) index[y] = r * f->max_rows + k * B + (y - b * B);
+        }
     }
 
     f->max_rows = std::max(1u, f->max_rows);
@@ -229,10 +269,6 @@ int frame_create_impl(const rtmi_camera* camera, const rtmi_object* objects, uin
     f->slice_words = slice_px * 4;
     for (uint32_t i = 0; i < n; ++i) {
         HIPF(hipSetDevice(devices[i]));
-        opt.device = devices[i];
-        const int rc = rtmi_scene_create(camera, objects, n_objects, materials, n_materials, &opt, &f->scenes[i]);
-        if (rc != RTMI_OK) return rc;
-        HIPF(hipStreamCreateWithFlags(&f->streams[i], hipStreamNonBlocking));
         HIPF(hipMalloc(reinterpret_cast<void**>(&f->d_slice[i]), f->slice_words * sizeof(uint32_t)));
         HIPF(hipMemset(f->d_slice[i], 0, f->slice_words * sizeof(uint32_t)));
     }
@@ -269,8 +305,11 @@ int frame_render_impl(rtmi_frame* f, uint64_t seed) {
     for (uint32_t i = 0; i < n; ++i) {
         const Shard& sh = f->shards[i];
         if (!sh.n_blocks) continue;
-        const int rc = rtmi_render_row_blocks_device(f->scenes[i], sh.y_first, f->block_rows, n, sh.n_blocks, seed,
-                                                     f->d_slice[i], f->d_slice[i] + (size_t)f->max_rows * W * 3, f->streams[i]);
+        const int rc = sh.blocks.empty()
+                           ? rtmi_render_row_blocks_device(f->scenes[i], sh.y_first, f->block_rows, n, sh.n_blocks, seed, f->d_slice[i],
+                                                           f->d_slice[i] + (size_t)f->max_rows * W * 3, f->streams[i])
+                           : rtmi_render_block_list_device(f->scenes[i], f->block_rows, sh.blocks.data(), sh.n_blocks, seed, f->d_slice[i],
+                                                           f->d_slice[i] + (size_t)f->max_rows * W * 3, f->streams[i]);
         if (rc != RTMI_OK) return rc;
     }
     HIPF(hipSetDevice(f->devices[0]));

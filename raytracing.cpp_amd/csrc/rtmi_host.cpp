@@ -751,6 +751,80 @@ uint32_t peel_top_leaves(const Bvh& bvh, uint32_t pre[4], uint32_t& n_pre) {
     return cur;
 }
 
+// Walks of scattered rays that start where the ray does (round 6; trees that stay in HBM).  A ray scattered off a sphere starts
+// INSIDE the box of every ancestor of that sphere's leaf, so a walk from the root descends to that leaf whatever the tree: on the
+// 100k-sphere grid of config 4, 15.1 of the 15.8 node trips of such a segment, with the sibling culled on 97 % of the levels
+// (tools/descent_score.py).  Any start node is exact as long as every subtree hanging off the path above it is still tested
+// (the closest hit does not depend on the visiting order), so: the walk starts at the sphere's own leaf (its
+// even-depth ancestor-or-self, at most kMaxWays * 2 levels down) with the WAY pre-loaded on its stack -- one record per two levels
+// of the path, holding the boxes and references of the two siblings that hang off the path there, IN THE NODE FORMAT: the
+// unchanged hand-written node step tests two levels a trip, pushes what it hits and pops the next record.  Round 5 built the same
+// idea with per-level sibling lists tested by a compiled loop at segment set-up and lost 14-31 %; the replay of the kernel's rounds
+// (tools/wave_replay.py grid) scored this form first: node trips per round 17.5 -> 13.2 on the grid.
+// Output: way records appended to `nodes` (indices >= the tree's node count), and per sphere SLOT one 64-byte start record
+// {start reference, n, way record indices top of the tree first (popped last), padding}; n = 0 and the walk's root where there is
+// no way (leaves one or two levels below the root, peeled leaves).
+void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& start_records) {
+    const uint32_t n_slots = (uint32_t)bvh.slot_object.size();
+    start_records.assign((size_t)n_slots * 16u, 0u);
+    for (uint32_t sl = 0; sl < n_slots; ++sl) start_records[(size_t)sl * 16u] = walk_root;
+    if (walk_root == kNoWalkRef || (walk_root & kLeafBit) || bvh.nodes.empty()) return;
+    const uint32_t n_nodes = (uint32_t)bvh.nodes.size();
+    // elements: internal nodes [0, n_nodes), then leaves in discovery order
+    struct El { uint32_t ref, parent, depth, side; };
+    std::vector<El> el(n_nodes);
+    std::vector<uint32_t> leaf_el; // per leaf element: index into el
+    std::vector<uint32_t> stack{walk_root};
+    el[walk_root] = El{walk_root, 0xffffffffu, 0u, 0u};
+    std::vector<uint32_t> slot_el(n_slots, 0xffffffffu);
+    while (!stack.empty()) {
+        const uint32_t n = stack.back();
+        stack.pop_back();
+        for (uint32_t k = 0; k < 2; ++k) {
+            const uint32_t c = bvh.nodes[n].child[k];
+            uint32_t e;
+            if (c & kLeafBit) {
+                e = (uint32_t)el.size();
+                el.push_back(El{});
+                const uint32_t first = c & 0x00ffffffu, cnt = (c >> 24) & 0x7fu;
+                for (uint32_t q = 0; q < cnt && first + q < n_slots; ++q) slot_el[first + q] = e;
+            } else {
+                e = c;
+                stack.push_back(c);
+            }
+            el[e] = El{c, n, el[n].depth + 1u, k};
+        }
+    }
+    constexpr uint32_t kMaxWays = 14; // ids of one 64-byte start record
+    std::vector<uint32_t> way_of(el.size(), 0xffffffffu);
+    auto way = [&](uint32_t e) { // the way record of even-depth element e (depth >= 2): the sibling of its parent, its own sibling
+        if (way_of[e] != 0xffffffffu) return way_of[e];
+        const uint32_t p = el[e].parent, g = el[p].parent;
+        rtmi_bvh_node v{};
+        const uint32_t sp = 1u - el[p].side, se = 1u - el[e].side;
+        // (copies: bvh.nodes grows below)
+        const rtmi_bvh_node ng = bvh.nodes[g], np = bvh.nodes[p];
+        std::memcpy(v.ctr[0], ng.ctr[sp], 12); std::memcpy(v.half[0], ng.half[sp], 12); v.child[0] = ng.child[sp];
+        std::memcpy(v.ctr[1], np.ctr[se], 12); std::memcpy(v.half[1], np.half[se], 12); v.child[1] = np.child[se];
+        way_of[e] = (uint32_t)bvh.nodes.size();
+        bvh.nodes.push_back(v);
+        return way_of[e];
+    };
+    for (uint32_t sl = 0; sl < n_slots; ++sl) {
+        uint32_t e = slot_el[sl];
+        if (e == 0xffffffffu) continue; // a peeled leaf
+        if (el[e].depth & 1u) e = el[e].parent;
+        while (el[e].depth > 2u * kMaxWays) e = el[el[e].parent].parent;
+        if (el[e].depth == 0u) continue;
+        uint32_t chain[kMaxWays], m = 0;
+        for (uint32_t x = e; el[x].depth >= 2u; x = el[el[x].parent].parent) chain[m++] = way(x);
+        uint32_t* r = &start_records[(size_t)sl * 16u];
+        r[0] = el[e].ref;
+        r[1] = m;
+        for (uint32_t i = 0; i < m; ++i) r[2u + i] = chain[m - 1u - i]; // top of the tree first: the deepest record is popped first
+    }
+}
+
 // Camera rays get an entry point (round 6).  Every sample of a pixel of one 8x8 tile is a ray from a point of the lens disk
 // through a point of the tile's rectangle on the focus plane (RayTracingCore::get_ray, core.cc:218-234: origin = cam_center +
 // dx disk_u + dy disk_v with dx^2 + dy^2 < 1, target = pixel00 + (x + ox) du + (y + oy) dv with ox, oy in [-0.5, 0.5)): at ray
@@ -956,6 +1030,74 @@ extern "C" int rtmi_tile_entries_build(const rtmi_camera* camera, const rtmi_obj
         return RTMI_ERR_OOM;
     } catch (...) {
         set_error("rtmi_tile_entries_build: unexpected exception");
+        return RTMI_ERR_INTERNAL;
+    }
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_shard_plan(uint32_t height, uint32_t block_rows, uint32_t n_ranks, const uint64_t* block_cost, uint32_t* rank_of_block_out) {
+    if (block_rows == 0 || n_ranks == 0 || (height && !rank_of_block_out)) {
+        set_error("rtmi_shard_plan: null argument, or block_rows / n_ranks of zero");
+        return RTMI_ERR_BAD_ARG;
+    }
+    const uint32_t nb = (height + block_rows - 1u) / block_rows;
+    if (!block_cost) {
+        for (uint32_t b = 0; b < nb; ++b) rank_of_block_out[b] = b % n_ranks;
+        return RTMI_OK;
+    }
+    try {
+        std::vector<uint32_t> order(nb);
+        for (uint32_t b = 0; b < nb; ++b) order[b] = b;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return block_cost[a] > block_cost[b]; });
+        std::vector<uint64_t> load(n_ranks, 0u);
+        std::vector<uint32_t> count(n_ranks, 0u);
+        const uint32_t cap = (nb + n_ranks - 1u) / n_ranks;
+        for (uint32_t b : order) {
+            uint32_t best = n_ranks;
+            for (uint32_t r = 0; r < n_ranks; ++r)
+                if (count[r] < cap && (best == n_ranks || load[r] < load[best] || (load[r] == load[best] && count[r] < count[best]))) best = r;
+            rank_of_block_out[b] = best;
+            load[best] += block_cost[b];
+            count[best]++;
+        }
+    } catch (...) {
+        set_error("rtmi_shard_plan: out of host memory");
+        return RTMI_ERR_OOM;
+    }
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_walk_starts_build(const rtmi_object* objects, uint32_t n_objects, uint32_t leaf_size, uint32_t bvh_passes,
+                                      rtmi_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* n_tree_nodes_out, uint32_t* records_out) {
+    if (n_objects && !objects) {
+        set_error("rtmi_walk_starts_build: null objects");
+        return RTMI_ERR_BAD_ARG;
+    }
+    for (uint32_t i = 0; i < n_objects; ++i) {
+        const rtmi_object& o = objects[i];
+        if (!std::isfinite(o.center[0]) || !std::isfinite(o.center[1]) || !std::isfinite(o.center[2]) || !std::isfinite(o.radius)) {
+            set_error("rtmi_walk_starts_build: object with a non-finite centre or radius");
+            return RTMI_ERR_BAD_ARG;
+        }
+    }
+    try {
+        Bvh bvh;
+        build_bvh(objects, n_objects, leaf_size ? leaf_size : (n_objects > 0x2000u ? 4u : 2u),
+                  bvh_passes ? bvh_passes - 1u : default_bvh_passes(n_objects), bvh);
+        const uint32_t n_tree = static_cast<uint32_t>(bvh.nodes.size());
+        uint32_t pre[4], n_pre = 0;
+        const uint32_t walk_root = peel_top_leaves(bvh, pre, n_pre);
+        std::vector<uint32_t> starts;
+        build_walk_starts(bvh, walk_root, starts);
+        if (n_nodes_out) *n_nodes_out = static_cast<uint32_t>(bvh.nodes.size());
+        if (n_tree_nodes_out) *n_tree_nodes_out = n_tree;
+        if (nodes_out && !bvh.nodes.empty()) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtmi_bvh_node));
+        if (records_out && !starts.empty()) std::memcpy(records_out, starts.data(), starts.size() * sizeof(uint32_t));
+    } catch (const std::bad_alloc&) {
+        set_error("rtmi_walk_starts_build: out of host memory");
+        return RTMI_ERR_OOM;
+    } catch (...) {
+        set_error("rtmi_walk_starts_build: unexpected exception");
         return RTMI_ERR_INTERNAL;
     }
     return RTMI_OK;

@@ -42,6 +42,9 @@ struct RtmiLaunch {
     // camera rays: where the walks of the samples of each 8x8 tile of the WHOLE image start (tile = (gy / 8) * gtiles_x + px / 8): a
     // node or leaf reference in the kernel variant's format, kStackEnd = the tile's beam meets no sphere of the tree; NULL: the root
     const uint32_t* tile_entry;
+    // scattered rays (HBM-resident trees): per sphere slot one 64-byte start record {reference the walk of a ray off that sphere starts
+    // at, n, indices of the n way records pre-loaded on its stack (top of the tree first)} (host: build_walk_starts); NULL: the root
+    const uint4* walk_starts;
     float pad_classes[kMaxPadClasses][8];
     uint32_t n_pad_classes;
     float pad_eps, pad_floor;
@@ -52,6 +55,9 @@ struct RtmiLaunch {
     uint32_t lds_top_nodes;   // HBM-resident trees: this many breadth-first nodes (48-byte records) start the LDS segment
     // image rows handled by this launch
     uint32_t y_first, block_rows, block_stride, n_local_rows;
+    // a launch over a LIST of row blocks instead of a strided set (rtmi_render_block_list_device): first image row of local block k
+    // (multiples of 8; block_rows a multiple of 8), NULL = block k starts at y_first + k * block_stride * block_rows
+    const uint32_t* block_first_row;
     uint32_t x_first, x_end, local_w; // columns [x_first, x_end) of every row (rtmi_render_rect; whole rows: 0, W, W); local_w = x_end - x_first
     uint32_t tiles_x, tiles_y, n_work; // work index space = tiles * 64
     FastDiv div_tiles_x, div_chunks, div_block_rows;

@@ -215,8 +215,28 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
         t.d = d;
         t.a = vdot(d, d);
         t.tbest = __builtin_inff();
+        const uint32_t origin_slot = t.best; // the sphere a scattered ray starts on (the hit it was scattered at); ~0u for a camera ray
         t.best = ~0u;
         t.sp = lds0 + P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT) + sp_stride; // entry 1 (entry 0: the sentinel)
+        if (ACCEL == RTMI_ACCEL_BVH && BIG && P.walk_starts != nullptr) {
+            // A ray scattered off a sphere of the tree starts its walk in that sphere's own leaf, the siblings hanging off the path
+            // above it pre-loaded on the stack as WAY records -- two levels a record, in the node format, so that the node loop
+            // tests them like any node (host: build_walk_starts; exact for any start).  One 64-byte record per slot.
+            if (origin_slot < P.n_slots) {
+                const uint4* R = P.walk_starts + 4u * origin_slot;
+                const uint4 r0 = R[0], r1 = R[1];
+                const uint32_t n = r0.y;
+                t.cur = r0.x;
+                auto push = [&](uint32_t k, uint32_t id) { if (k < n) *stack_at(t.sp + k * sp_stride) = (StackS)id; };
+                push(0u, r0.z); push(1u, r0.w); push(2u, r1.x); push(3u, r1.y); push(4u, r1.z); push(5u, r1.w);
+                if (ballot(n > 6u) != 0ull) {
+                    const uint4 r2 = R[2], r3 = R[3];
+                    push(6u, r2.x); push(7u, r2.y); push(8u, r2.z); push(9u, r2.w);
+                    push(10u, r3.x); push(11u, r3.y); push(12u, r3.z); push(13u, r3.w);
+                }
+                t.sp += n * sp_stride;
+            }
+        }
         if (ACCEL == RTMI_ACCEL_BVH) { // (t.cur, where the walk starts, was set by whoever made the segment: the root, or a camera ray's entry)
             t.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
             PF_MARK(17);
@@ -314,8 +334,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                         flip = 0u;
                     }
                     const uint32_t trow = fdiv(tile, P.div_tiles_x);
-                    pool[2] = (tile - trow * P.tiles_x) | ((flip ? P.tiles_y - 1u - trow : trow) << 16);
-                    pool[3] = s0;
+                    const uint32_t trow_l = flip ? P.tiles_y - 1u - trow : trow;
+                    pool[2] = (tile - trow * P.tiles_x) | (trow_l << 16);
+                    // (a launch over a LIST of row blocks -- the cost-balanced shards of a multi-GPU frame: blocks of a multiple of 8
+                    // rows that start on multiples of 8 -- looks the tile's image row up once per refill: bits 16.. = that row / 8)
+                    uint32_t gy8 = 0u;
+                    if (P.block_first_row != nullptr && next < P.n_work) {
+                        const uint32_t ply0 = trow_l * 8u, blk0 = fdiv(ply0, P.div_block_rows);
+                        gy8 = (P.block_first_row[blk0] + (ply0 - blk0 * P.block_rows)) >> 3;
+                    }
+                    pool[3] = s0 | (gy8 << 16); // (s0 < samples_per_pixel <= 65535)
                 }
                 take = min((uint32_t)__popcll(need), end - next);
                 start = next;
@@ -336,11 +364,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                 const uint32_t j = idx & 63u;
                 const uint32_t px = P.x_first + (txy & 0xffffu) * 8u + (j & 7u), ply = (txy >> 16) * 8u + (j >> 3);
                 if (px < P.x_end && ply < P.n_local_rows) {
-                    const uint32_t blk = fdiv(ply, P.div_block_rows); // local row -> row of the whole image
-                    const uint32_t gy = P.y_first + blk * P.block_stride * P.block_rows + (ply - blk * P.block_rows);
+                    uint32_t gy; // local row -> row of the whole image
+                    if (P.block_first_row != nullptr) {
+                        gy = ((s_first >> 16) << 3) + (j >> 3);
+                    } else {
+                        const uint32_t blk = fdiv(ply, P.div_block_rows);
+                        gy = P.y_first + blk * P.block_stride * P.block_rows + (ply - blk * P.block_rows);
+                    }
                     lpix = ply * P.local_w + (px - P.x_first);
                     rng.pixel = gy * W + px;
-                    s = s_first;
+                    s = s_first & 0xffffu;
                     s_end = min(spp, s + P.chunk);
                     if (WHOLE) sum = mk(0.0f, 0.0f, 0.0f);
                     phase = PH_GEN;
@@ -407,6 +440,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             } else {
                 t.o = origin;
                 t.d = vsub(pixel_sample, origin);
+                if (ACCEL == RTMI_ACCEL_BVH && BIG) t.best = ~0u; // (begin_segment reads where a scattered ray starts from t.best)
                 phase = PH_BEGIN;
             }
         }
@@ -746,6 +780,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                 s++;
                 if (STATS) st_samples++;
                 if (STATS && P.tile_cost != nullptr && s >= s_end) { // probe launch: what this work item cost, into its tile of the whole image
+                    // (its ray segments.  Round 6 tried the TIME the lane held the item instead -- a segment of a path trapped inside
+                    // the ground sphere costs half an average one -- and it predicted worse: 11.05 against 10.85 ms on config 2, the
+                    // 8-way shards 12 % apart instead of 4 %: a lane's rounds last as long as its wave's slowest walk.)
                     const uint32_t gy_c = fdiv(rng.pixel, P.div_w), px_c = rng.pixel - gy_c * W;
                     atomicAdd(&P.tile_cost[(gy_c >> 3) * P.gtiles_x + (px_c >> 3)], st_segments - st_item0);
                     st_item0 = st_segments;

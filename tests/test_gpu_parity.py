@@ -174,7 +174,7 @@ def test_launch_info_reports_what_the_tuning_resolved_to(pkg, rtow, gpu):
     for cap, want_top in ((0, None), (1, 0), (41, 40)):
         with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(force_hbm_scene=1, lds_top_nodes=cap)) as s:
             li3 = s.launch_info()
-            assert li3["scene_in_lds"] == 0 and li3["lds_top_nodes"] == (len(s.bvh()["nodes"]) if want_top is None else want_top)
+            assert li3["scene_in_lds"] == 0 and li3["lds_top_nodes"] == (s.bvh()["n_tree_nodes"] if want_top is None else want_top)
             assert li3["pad_mode"] == 1
     with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BRUTE) as s:
         assert s.launch_info()["pad_mode"] == 0 and s.launch_info()["lds_top_nodes"] == 0
@@ -611,17 +611,83 @@ def test_multi_device_frame_entry_degenerate_one_device(pkg, ob, rtow, gpu):
         assert rgb.tobytes() == ref.tobytes() and np.array_equal(rgba, ref8)
     # n > 1 on one box: the rehearsal hook lists the device several times and gathers with copies instead of RCCL; the
     # shard plan (interleaved blocks, ragged last block), the rank-major gather layout and the scanline order are the real ones
-    for devices, block_rows in (((0, 0), 8), ((0, 0, 0), 5), ((0,) * 8, 8), ((0,) * 7, 3)):
-        with pkg.Frame(cam, *rtow, devices=devices, block_rows=block_rows, rehearsal=True) as f:
+    # (tile_order 2: the scenes probe their cost map even for this small frame, so that blocks of whole tile rows are dealt out by
+    # cost -- rtmi_shard_plan -- and rendered through rtmi_render_block_list_device; blocks of 5 or 3 rows stay block b -> device b mod n)
+    for devices, block_rows, tun in (((0, 0), 8, None), ((0, 0, 0), 5, None), ((0,) * 8, 8, None), ((0,) * 7, 3, None),
+                                     ((0, 0), 8, dict(tile_order=2)), ((0,) * 3, 16, dict(tile_order=2)), ((0,) * 8, 8, dict(tile_order=2)),
+                                     ((0,) * 3, 5, dict(tile_order=2))):
+        with pkg.Frame(cam, *rtow, devices=devices, block_rows=block_rows, rehearsal=True, tuning=tun, cost_plan=tun is not None) as f:
             rgb, rgba = f.render(21)
             assert f.rccl_ranks == 0 and len(f.timing()["kernel_ms"]) == len(devices)
-        assert rgb.tobytes() == ref.tobytes() and np.array_equal(rgba, ref8), (devices, block_rows)
+        assert rgb.tobytes() == ref.tobytes() and np.array_equal(rgba, ref8), (devices, block_rows, tun)
     n_dev = torch.cuda.device_count()
     for devices in ((0, 0), (n_dev,), (-1,)):
         with pytest.raises(pkg.RtmiError) as e:
             pkg.Frame(cam, *rtow, devices=devices)
         assert e.value.code == pkg.RTMI_ERR_BAD_ARG
     assert torch.cuda.current_device() == 0  # every entry point restores the caller's device
+
+
+def test_block_lists_and_the_cost_balanced_shard_plan(pkg, ob, rtow, gpu):
+    """row blocks dealt out to the ranks by the scene's cost map (rtmi_shard_plan: longest processing time first, the
+    same number of blocks to every rank) and rendered as a LIST (rtmi_render_block_list_device).  Any list gives the rows it names,
+    bit for bit -- ascending, shuffled, with the image's clipped last block, in bands, trees in LDS and in HBM -- and the plan made
+    from the scene's own probe balances the ranks' costs no worse than block b -> rank b mod N."""
+    torch = gpu
+    kw = dict(image_width=200, samples_per_pixel=8, max_depth=50)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    W, H = cam.img_width, cam.img_height  # 200 x 112 = 14 blocks of 8 rows
+    want, want8 = ob.render_rect_counter(ocam, *rtow, 23, 0, 0, W, H, nthreads=8)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rng = np.random.default_rng(3)
+    for tun in (dict(tile_order=2), dict(tile_order=2, bands=3), dict(force_hbm_scene=1), dict(tile_order=1, chunk_samples=3)):
+        with pkg.Scene(cam, *rtow, tuning=tun) as s:
+            costs = s.tile_costs()
+            assert (costs is not None) == (tun.get("tile_order") == 2)
+            for world in (2, 3, 8):
+                bc = pkg.block_costs(costs, H, 8) if costs is not None else None
+                plan = pkg.CostShardPlan(H, 8, world, bc)
+                parts = [torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev) for _ in range(world)]
+                parts8 = [torch.zeros((plan.max_rows, W), dtype=torch.int32, device=dev) for _ in range(world)]
+                for r in range(world):
+                    if len(plan.blocks(r)):
+                        s.render_block_list_device(8, plan.blocks(r), 23, parts[r].data_ptr(), parts8[r].data_ptr(), stream)
+                torch.cuda.synchronize()
+                idx = torch.as_tensor(plan.index, device=dev)
+                _assert_frames_equal(torch.cat(parts, 0).index_select(0, idx).cpu().numpy(), want)
+                assert np.array_equal(torch.cat(parts8, 0).index_select(0, idx).cpu().numpy().view(np.uint32), want8)
+                if bc is not None and world <= 3:
+                    loads = [int(bc[plan.blocks(r)].sum()) for r in range(world)]
+                    mod = [int(bc[np.arange(len(bc)) % world == r].sum()) for r in range(world)]
+                    assert max(loads) <= max(mod), (loads, mod)
+            # a shuffled list: the slice holds the blocks in list order
+            blocks = rng.permutation(H // 8).astype(np.uint32)[:9]
+            buf = torch.zeros((len(blocks) * 8, W, 3), dtype=torch.float32, device=dev)
+            s.render_block_list_device(8, blocks, 23, buf.data_ptr(), 0, stream)
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy()
+            for k, b in enumerate(blocks):
+                _assert_frames_equal(got[8 * k:8 * k + 8], want[8 * b:8 * b + 8])
+            with pytest.raises(pkg.RtmiError) as err:  # tiles must not straddle blocks
+                s.render_block_list_device(5, np.array([0, 2], np.uint32), 23, buf.data_ptr(), 0, stream)
+            assert err.value.code == pkg.RTMI_ERR_BAD_ARG
+            with pytest.raises(pkg.RtmiError) as err:  # a block outside the image
+                s.render_block_list_device(8, np.array([0, 99], np.uint32), 23, buf.data_ptr(), 0, stream)
+            assert err.value.code == pkg.RTMI_ERR_BAD_ARG
+    # an image whose last block is clipped, blocks of 16 rows
+    kw = dict(image_width=178, samples_per_pixel=4, max_depth=20)
+    cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+    W, H = cam.img_width, cam.img_height
+    assert H % 16 != 0
+    want, _ = ob.render_rect_counter(ocam, *rtow, 4, 0, 0, W, H, nthreads=8)
+    with pkg.Scene(cam, *rtow, tuning=dict(tile_order=2)) as s:
+        plan = pkg.CostShardPlan(H, 16, 3, pkg.block_costs(s.tile_costs(), H, 16))
+        parts = [torch.zeros((plan.max_rows, W, 3), dtype=torch.float32, device=dev) for _ in range(3)]
+        for r in range(3):
+            s.render_block_list_device(16, plan.blocks(r), 4, parts[r].data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        _assert_frames_equal(torch.cat(parts, 0).index_select(0, torch.as_tensor(plan.index, device=dev)).cpu().numpy(), want)
 
 
 def test_rccl_runs_with_a_one_rank_communicator(pkg, rtow, gpu):
@@ -865,6 +931,48 @@ def test_cost_ordered_tiles_and_sequential_bands_do_not_change_the_image(pkg, ob
     assert err.value.code == pkg.RTMI_ERR_BAD_ARG
 
 
+def test_walk_starts_of_scattered_rays_do_not_change_the_image(pkg, ob, rtow, gpu):
+    """rtmi_tuning::walk_start (0.6): on trees that stay in HBM the walk of a scattered ray starts in the leaf of the sphere it was
+    scattered off, the way above it pre-loaded on the stack (host data: tests/test_host_cpu.py::test_walk_starts_keep_the_walk_exact).
+    Same frame as the oracle's linear scan with it on (default) and off, with and without camera entries and the staged top of the
+    tree, whole-pixel items, both pad rules; and exactly the box and sphere tests of the oracle's walk that follows the same
+    records -- fewer than from the root."""
+    worlds = [(*rtow, dict(image_width=160, samples_per_pixel=6, max_depth=50))]
+    objs, mats, kw = big_grid(90, seed=6)
+    worlds.append((objs, mats, dict(kw, image_width=128, samples_per_pixel=4, max_depth=30)))
+    for objs, mats, kw in worlds:
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        W, H = cam.img_width, cam.img_height
+        want, want8 = ob.render_rect_counter(ocam, objs, mats, 17, 0, 0, W, H, nthreads=8)
+        tests = {}
+        for tun in (dict(), dict(walk_start=1), dict(cam_entry=2), dict(lds_top_nodes=1), dict(chunk_samples=-1, pad_mode=1),
+                    dict(pad_mode=2, lds_top_nodes=9, block_lanes=512)):
+            with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=dict(tun, force_hbm_scene=1)) as s:
+                li = s.launch_info()
+                assert li["scene_in_lds"] == 0 and li["walk_start"] == (0 if tun.get("walk_start") else 1), (tun, li)
+                rgb, rgba = s.render_rows(0, H, 17)
+                st = s.stats()
+                bvh = s.bvh()
+                assert (bvh["walk_starts"] is not None) == (li["walk_start"] == 1)
+                _assert_frames_equal(rgb, want)
+                assert np.array_equal(rgba, want8)
+                if tun in (dict(), dict(walk_start=1), dict(cam_entry=2)):
+                    ob.set_pad_mode(li["pad_mode"])
+                    try:
+                        _, _, c = ob.render_rect_counter(ocam, objs, mats, 17, 0, 0, W, H, nthreads=8, counters=True, bvh=bvh)
+                    finally:
+                        ob.set_pad_mode(0)
+                    assert st["segments"] == c["segments"]
+                    assert abs(st["node_tests"] - c["node_tests"]) <= 1e-3 * c["node_tests"], (tun, st, c)
+                    assert abs(st["sphere_tests"] - c["sphere_tests"]) <= 1e-3 * c["sphere_tests"], (tun, st, c)
+                    tests[tun.get("walk_start", 0)] = st["node_tests"]
+                part, _ = s.render_rows(3, 50, 17)
+                _assert_frames_equal(part, want[3:50])
+        assert tests[0] < 0.9 * tests[1], tests
+    with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH) as s:  # trees staged into LDS have no room for the records
+        assert s.launch_info()["walk_start"] == 0 and s.bvh()["walk_starts"] is None
+
+
 def test_record_buffers_of_several_scenes_never_exceed_the_device(pkg, rtow, gpu):
     """scenes keep their sample-record buffers between calls, and the cap on one band's records used to come from the
     device's TOTAL memory (a third of it), whatever else lived there.  Several scenes on one device whose record buffers together
@@ -1050,7 +1158,7 @@ def test_leaves_peeled_off_the_top_of_the_tree(pkg, ob, gpu):
     for n_walls, n_cluster in ((1, 24), (2, 24), (3, 24), (5, 24), (2, 0), (3, 1), (4, 0), (1, 1)):
         objs, mats = arrays(walls[:n_walls] + cluster[:n_cluster])
         bvh = pkg.bvh_build(objs)
-        bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
+        bvh = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE), entries=pkg.tile_entries_build(cam, objs))  # (what the scene does)
         want, want8, c = ob.render_rect_counter(ocam, objs, mats, 9, 0, 0, ocam.img_width, ocam.img_height, counters=True,
                                                 bvh=bvh, nthreads=8)
         with pkg.Scene(cam, objs, mats, accel=pkg.ACCEL_BVH, collect_stats=True) as s:

@@ -248,6 +248,44 @@ def test_camera_tile_entries_keep_the_walk_exact(pkg, ob, rtow):
     assert skipped > 0.05 * walked  # (S-RTOW at 1080p: camera rays 8.9 -> 2.0 node trips each, tools/wave_replay.py)
 
 
+def test_walk_starts_keep_the_walk_exact(pkg, ob, rtow):
+    """rtmi_tuning::walk_start (0.6, trees that stay in HBM): the walk of a ray scattered off a sphere starts in that sphere's own
+    leaf, the siblings hanging off the path above it pre-loaded on the stack as way records (two levels a record, in the node
+    format).  Host data (rtmi_walk_starts_build, no device): the oracle's walk FOLLOWING it must give the oracle's linear scan float
+    for float -- S-RTOW, a jittered grid, the fuzz worlds (negative radii, nested spheres, one-sphere worlds, every leaf size) --
+    with fewer box tests; every record is well formed (way records only behind the tree's nodes, every sibling of the path in
+    exactly one of them)."""
+    from tests.scenes import big_grid
+    cases = [(*rtow, dict(image_width=120, samples_per_pixel=3, max_depth=16), 2)]
+    o, m, kw = big_grid(40, seed=2)
+    cases.append((o, m, dict(kw, image_width=96, samples_per_pixel=3, max_depth=16), 4))
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        o, m, kw = pkg.workloads.fuzz_world(rng, case)
+        cases.append((o, m, dict(kw, max_depth=min(kw["max_depth"], 8)), int(rng.choice([1, 2, 3, 4]))))
+    saved = total = 0
+    for objs, mats, kw, leaf in cases:
+        cam, ocam = pkg.camera_setup(pkg.camera_params(**kw)), ob.camera_setup(ob.camera_params(**kw))
+        W, H = cam.img_width, cam.img_height
+        want, _ = ob.render_rect_counter(ocam, objs, mats, 5, 0, 0, W, H, nthreads=8)
+        bvh = pkg.bvh_build(objs, leaf)
+        nodes, n_tree, rec = pkg.walk_starts_build(objs, leaf)
+        assert n_tree == len(bvh["nodes"]) and nodes[:n_tree].tobytes() == bvh["nodes"].tobytes()
+        assert rec.shape == (len(objs), 16) and (rec[:, 1] <= 14).all()
+        ways = rec[:, 2:][np.arange(14)[None, :] < rec[:, 1:2]]
+        assert ((ways >= n_tree) & (ways < len(nodes))).all()  # way records sit behind the tree's own nodes
+        base = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
+        _, _, c0 = ob.render_rect_counter(ocam, objs, mats, 5, 0, 0, W, H, nthreads=8, counters=True, bvh=base)
+        got, _, c1 = ob.render_rect_counter(ocam, objs, mats, 5, 0, 0, W, H, nthreads=8, counters=True,
+                                            bvh=dict(base, nodes=nodes.view(ob.BVH_NODE_DTYPE), walk_starts=rec))
+        a, b = np.nan_to_num(got, nan=-1.0).view(np.uint32), np.nan_to_num(want, nan=-1.0).view(np.uint32)
+        assert np.array_equal(a, b), (kw, int((a != b).any(axis=-1).sum()))
+        assert c1["segments"] == c0["segments"]
+        saved += c0["node_tests"] - c1["node_tests"]
+        total += c0["node_tests"]
+    assert saved > 0.1 * total
+
+
 @pytest.mark.parametrize("height,block,world", [(1080, 8, 1), (1080, 8, 8), (675, 8, 2), (675, 8, 4), (225, 16, 8),
                                                 (7, 8, 4), (54, 8, 3)])
 def test_row_block_sharding_covers_every_row_once(pkg, height, block, world):
