@@ -185,7 +185,8 @@ struct rtmi_scene {
     uint32_t wait_thresh = 52; // (scene_create: 56 for trees staged into LDS since camera rays have entries, round 6: 126.6 against 127.8 ms)
 
     uint32_t lds_att = 0, lds_pool = 0;
-    uint32_t lds_top_nodes = 0; // HBM-resident trees: breadth-first nodes staged into LDS (48-byte records at the start of the segment)
+    uint32_t lds_top_nodes = 0; // HBM-resident trees: records staged into LDS (48 bytes each, the start of the device array): breadth-first nodes ...
+    uint32_t lds_top_ways = 0;  // ... of which this many are the shallowest way records (rtmi_tuning::walk_start)
     uint32_t n_cus = 0;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     uint32_t pre_leaf_dev[4] = {}; // leaves peeled off the top of the tree, tested at segment set-up
@@ -896,6 +897,16 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         s->block = 896u;
         while (s->block > 768u && (uint64_t)s->stack_depth * s->block * 4u + (s->block / 64u) * 80u + 64u > 80u * 1024u) s->block -= 64u;
     }
+    // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start every walk below them
+    uint32_t walk_root = s->bvh.root_ref, pre[4] = {};
+    if (s->accel == RTMI_ACCEL_BVH && !s->bvh.nodes.empty()) walk_root = peel_top_leaves(s->bvh, pre, s->n_pre_leaves);
+    // scattered rays of trees that stay in HBM start in their own leaf (rtmi_tuning::walk_start): way records behind the nodes
+    std::vector<uint32_t> starts, node_perm, way_depth; // node_perm: builder's node index -> position in the device array (empty: identity)
+    if (s->accel == RTMI_ACCEL_BVH && s->big && tune.walk_start != 1u && walk_root != kNoWalkRef && !(walk_root & kLeafBit) &&
+        !s->bvh.nodes.empty()) {
+        build_walk_starts(s->bvh, walk_root, starts, &way_depth);
+        if (s->bvh.nodes.size() == s->n_tree_nodes) starts.clear(); // (no sphere has a way: a tree of two levels)
+    }
     uint32_t off = 0;
     if (!s->big) {
         s->lds_nodes = off;
@@ -913,9 +924,36 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         // levels and half of the ninth (rtmi_tuning::lds_top_nodes caps it: n > 0 = at most n - 1 nodes)
         const uint64_t fixed = (uint64_t)s->stack_depth * s->block * 4u + (uint64_t)(s->block / 64u) * 80u + 64u;
         uint64_t k = fixed < 80u * 1024u ? (80u * 1024u - fixed) / 48u : 0u;
-        k = std::min<uint64_t>(k, s->bvh.nodes.size());
+        k = std::min<uint64_t>(k, s->bvh.nodes.size()); // (way records included)
         if (tune.lds_top_nodes) k = std::min<uint64_t>(k, tune.lds_top_nodes - 1u);
         s->lds_top_nodes = (uint32_t)k;
+        // The staged records are shared between the tree's first breadth-first nodes and the SHALLOWEST way records: scattered rays
+        // never read the top nodes any more, they read the way records of their path's top levels -- which many leaves share (4 + 16 +
+        // 64 + 256 records cover the levels down to 8) -- and with every way record in memory the scheme measured +2 % SLOWER than
+        // walks from the root on config 4, whose first 8 levels had been LDS reads.  The device array is a permutation of bvh.nodes:
+        // [top nodes | top ways | other nodes | other ways]; every reference handed to the device goes through node_perm; what the
+        // library exports (rtmi_scene_get_bvh, rtmi_scene_get_walk_starts) keeps the builder's numbering.
+        if (!starts.empty() && k != 0u) {
+            const uint32_t n_tree = s->n_tree_nodes, n_all = (uint32_t)s->bvh.nodes.size(), kk = (uint32_t)k;
+            std::vector<uint32_t> by_depth(n_all - n_tree);
+            for (uint32_t i = 0; i < by_depth.size(); ++i) by_depth[i] = i;
+            std::stable_sort(by_depth.begin(), by_depth.end(), [&](uint32_t a, uint32_t b) { return way_depth[a] < way_depth[b]; });
+            // whole levels of ways while at least 31 slots (five levels of nodes) stay for the tree's own top
+            uint32_t k2 = 0;
+            while (k2 < by_depth.size()) {
+                uint32_t e = k2;
+                while (e < by_depth.size() && way_depth[by_depth[e]] == way_depth[by_depth[k2]]) ++e;
+                if (e + std::min(31u, n_tree) > kk) break;
+                k2 = e;
+            }
+            const uint32_t k1 = std::min(n_tree, kk - k2);
+            node_perm.assign(n_all, 0u);
+            for (uint32_t i = 0; i < n_tree; ++i) node_perm[i] = i < k1 ? i : i + k2;
+            for (uint32_t j = 0; j < by_depth.size(); ++j) node_perm[n_tree + by_depth[j]] = j < k2 ? k1 + j : n_tree + j;
+            s->lds_top_nodes = k1 + k2;
+            s->lds_top_ways = k2;
+            k = s->lds_top_nodes;
+        }
         off = align16((uint32_t)k * 48u);
     }
     s->lds_stack = off;
@@ -957,17 +995,6 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     HIP_TRY_S(upload(&s->d_aux, h_aux.data(), h_aux.size() * sizeof(uint4)));
     HIP_TRY_S(upload(&s->d_mats, h_mats.data(), h_mats.size() * sizeof(uint4)));
     {
-        // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start
-        // every walk below them
-        uint32_t walk_root = s->bvh.root_ref, pre[4] = {};
-        if (s->accel == RTMI_ACCEL_BVH && !s->bvh.nodes.empty()) walk_root = peel_top_leaves(s->bvh, pre, s->n_pre_leaves);
-        // scattered rays of trees that stay in HBM start in their own leaf (rtmi_tuning::walk_start): way records behind the nodes
-        std::vector<uint32_t> starts;
-        if (s->accel == RTMI_ACCEL_BVH && s->big && tune.walk_start != 1u && walk_root != kNoWalkRef && !(walk_root & kLeafBit) &&
-            !s->bvh.nodes.empty()) {
-            build_walk_starts(s->bvh, walk_root, starts);
-            if (s->bvh.nodes.size() == s->n_tree_nodes) starts.clear(); // (no sphere has a way: a tree of two levels)
-        }
         // device copy of the nodes: LDS-resident scenes get their references in the 16-bit stack-entry form
         std::vector<rtmi_bvh_node> dn = s->bvh.nodes;
         // (leaf references are stored sign-extended: as 32-bit integers nodes are >= 0, leaves < -1 and the stack's
@@ -983,7 +1010,11 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
             }
             s->root_ref_dev = pack16(s->bvh.root_ref);
         }
-        auto dev_ref = [&](uint32_t ref) { return ref == kNoWalkRef ? kNoWalk : (s->big ? ref : pack16(ref)); };
+        auto dev_ref = [&](uint32_t ref) {
+            if (ref == kNoWalkRef) return kNoWalk;
+            if (!s->big) return pack16(ref);
+            return (!(ref & kLeafBit) && !node_perm.empty()) ? node_perm[ref] : ref;
+        };
         if (s->accel == RTMI_ACCEL_BVH && !dn.empty()) {
             for (uint32_t q = 0; q < s->n_pre_leaves; ++q) s->pre_leaf_dev[q] = dev_ref(pre[q]);
             if (s->n_pre_leaves) s->root_ref_dev = dev_ref(walk_root);
@@ -1011,7 +1042,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
             };
             std::vector<uint32_t> rec(dn.size() * 12u, 0u);
             for (size_t i = 0; i < dn.size(); ++i) {
-                uint32_t* r = &rec[i * 12u];
+                uint32_t* r = &rec[(node_perm.empty() ? i : (size_t)node_perm[i]) * 12u];
                 for (int k = 0; k < 2; ++k)
                     for (int a = 0; a < 3; ++a) r[k * 3 + a] = fbits(dn[i].ctr[k][a]);
                 uint16_t hb[6];
@@ -1023,12 +1054,18 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
                 r[6] = hb[0] | ((uint32_t)hb[1] << 16);
                 r[7] = hb[2] | ((uint32_t)hb[3] << 16);
                 r[8] = hb[4] | ((uint32_t)hb[5] << 16);
-                r[9] = dn[i].child[0];
-                r[10] = dn[i].child[1];
+                r[9] = s->big ? dev_ref(dn[i].child[0]) : dn[i].child[0]; // (trees in LDS: packed above)
+                r[10] = s->big ? dev_ref(dn[i].child[1]) : dn[i].child[1];
             }
             HIP_TRY_S(upload(&s->d_nodes, rec.data(), rec.size() * sizeof(uint32_t)));
             if (!starts.empty()) {
-                HIP_TRY_S(upload(&s->d_walk_starts, starts.data(), starts.size() * sizeof(uint32_t)));
+                std::vector<uint32_t> dev_starts = starts;
+                for (size_t sl = 0; sl < dev_starts.size() / 16u; ++sl) {
+                    uint32_t* r = &dev_starts[sl * 16u];
+                    r[0] = dev_ref(r[0]);
+                    for (uint32_t q = 0; q < r[1] && q < 14u; ++q) r[2u + q] = dev_ref(r[2u + q]);
+                }
+                HIP_TRY_S(upload(&s->d_walk_starts, dev_starts.data(), dev_starts.size() * sizeof(uint32_t)));
                 s->walk_starts.swap(starts);
             }
             // camera rays start at their tile's entry (rtmi_tuning::cam_entry; host: build_tile_entries, csrc/rtmi_host.cpp)

@@ -764,7 +764,7 @@ uint32_t peel_top_leaves(const Bvh& bvh, uint32_t pre[4], uint32_t& n_pre) {
 // Output: way records appended to `nodes` (indices >= the tree's node count), and per sphere SLOT one 64-byte start record
 // {start reference, n, way record indices top of the tree first (popped last), padding}; n = 0 and the walk's root where there is
 // no way (leaves one or two levels below the root, peeled leaves).
-void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& start_records) {
+void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& start_records, std::vector<uint32_t>* way_depth) {
     const uint32_t n_slots = (uint32_t)bvh.slot_object.size();
     start_records.assign((size_t)n_slots * 16u, 0u);
     for (uint32_t sl = 0; sl < n_slots; ++sl) start_records[(size_t)sl * 16u] = walk_root;
@@ -808,6 +808,7 @@ void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& star
         std::memcpy(v.ctr[1], np.ctr[se], 12); std::memcpy(v.half[1], np.half[se], 12); v.child[1] = np.child[se];
         way_of[e] = (uint32_t)bvh.nodes.size();
         bvh.nodes.push_back(v);
+        if (way_depth) way_depth->push_back(el[e].depth); // (the deeper of the two levels the record covers)
         return way_of[e];
     };
     for (uint32_t sl = 0; sl < n_slots; ++sl) {
@@ -1088,7 +1089,7 @@ extern "C" int rtmi_walk_starts_build(const rtmi_object* objects, uint32_t n_obj
         uint32_t pre[4], n_pre = 0;
         const uint32_t walk_root = peel_top_leaves(bvh, pre, n_pre);
         std::vector<uint32_t> starts;
-        build_walk_starts(bvh, walk_root, starts);
+        build_walk_starts(bvh, walk_root, starts, nullptr);
         if (n_nodes_out) *n_nodes_out = static_cast<uint32_t>(bvh.nodes.size());
         if (n_tree_nodes_out) *n_tree_nodes_out = n_tree;
         if (nodes_out && !bvh.nodes.empty()) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtmi_bvh_node));

@@ -174,7 +174,7 @@ def test_launch_info_reports_what_the_tuning_resolved_to(pkg, rtow, gpu):
     for cap, want_top in ((0, None), (1, 0), (41, 40)):
         with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(force_hbm_scene=1, lds_top_nodes=cap)) as s:
             li3 = s.launch_info()
-            assert li3["scene_in_lds"] == 0 and li3["lds_top_nodes"] == (s.bvh()["n_tree_nodes"] if want_top is None else want_top)
+            assert li3["scene_in_lds"] == 0 and li3["lds_top_nodes"] == (len(s.bvh()["nodes"]) if want_top is None else want_top)  # (way records included)
             assert li3["pad_mode"] == 1
     with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BRUTE) as s:
         assert s.launch_info()["pad_mode"] == 0 and s.launch_info()["lds_top_nodes"] == 0
