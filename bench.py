@@ -391,8 +391,8 @@ def main(argv=None):
             return f, f8
 
         def step():
-            if n_blocks and world == 1:
-                scene.render_row_blocks_device(0, BLOCK_ROWS, 1, n_blocks, RENDER_SEED, rgb.data_ptr(), rgba.data_ptr(), stream)
+            if n_blocks and (world == 1 or not bc.any()):  # block b -> rank b mod N: the strided set of rounds 1-5
+                scene.render_row_blocks_device(rank * BLOCK_ROWS, BLOCK_ROWS, world, n_blocks, RENDER_SEED, rgb.data_ptr(), rgba.data_ptr(), stream)
             elif n_blocks:
                 scene.render_block_list_device(BLOCK_ROWS, my_blocks, RENDER_SEED, rgb.data_ptr(), rgba.data_ptr(), stream)
             if not use_dist:
@@ -675,6 +675,9 @@ def main(argv=None):
                 "note": "rtmi_trace_kernel<brute>: the reference's O(N) scan (object.defs.cc:68-81); the BVH walk returns "
                         "the same frame with far less algorithmic work",
             }
+            # the normaliser for lines from different boxes: the walk's kernel time per sample over the scan's, both
+            # measured in this run on this box (the scan is 94 % of its roofline and its code moves little between rounds)
+            out["walk_over_scan_kernel_ratio"] = round((max(per_rank_ms) / samples) / (lin_ms / lin_samples), 5)
         # ---- CPU baseline: the oracle, reference-shaped job system, on this host's cores -----------------------
         if world == 1 and not args.single_process and not args.no_cpu_baseline:
             hw = usable_cpus()

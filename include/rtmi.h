@@ -107,7 +107,7 @@ typedef struct rtmi_tuning {
     uint32_t struct_size;       /* = sizeof(rtmi_tuning) */
     uint32_t block_lanes;       /* lanes per workgroup, multiple of 64 (default 768: 2 x 768 per CU = 6 waves per SIMD) */
     uint32_t blocks_per_cu;     /* cap on resident workgroups per CU (default: the occupancy query) */
-    uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 52; 56 for trees staged into LDS whose camera rays have entries) */
+    uint32_t wait_thresh;       /* lanes waiting for shading that end a traversal round (default 52; 56 for trees staged into LDS whose camera rays have entries, 44 for trees in HBM with walk starts) */
     uint32_t pad_mode;          /* BVH box pad per ray segment: 1 = the class pad of rounds 1-3 (from the farthest centre of each
                                  * radius class), 2 = that pad bounded by the reach of the segment, 0 = default: 2 on scenes
                                  * much wider than their spheres (where it pays), else 1; same image in every mode.
@@ -140,8 +140,9 @@ typedef struct rtmi_tuning {
     /* ---- added in 0.6 ---- */
     uint32_t cam_entry;         /* camera rays start their walk at the entry of their 8x8 tile -- the lowest common ancestor of every
                                  * sphere the tile's beam (lens disk x tile rectangle on the focus plane) can meet, nowhere when it meets
-                                 * none -- instead of the root: 0 = for trees staged into LDS (measured: -3.2 % on the 1080p S-RTOW frame,
-                                 * +2.7 % on the HBM-resident 100k-sphere tree, whose top levels are the cheap ones), 1 = off, 2 = always */
+                                 * none -- instead of the root: 0 = for trees staged into LDS (measured: -3.2 % on the 1080p S-RTOW frame)
+                                 * and for trees in HBM whose scattered rays start in their own leaf (walk_start; alone it cost the
+                                 * 100k-sphere tree +2.7 %: the levels it skips are the staged, cheap ones), 1 = off, 2 = always */
     uint32_t walk_start;        /* where the walks of scattered rays start: 0 = default -- on trees that stay in HBM, in the leaf of the sphere
                                  * the ray was scattered off, the siblings hanging off the path above it pre-loaded on the stack as way
                                  * records (two levels a record, in the node format); at the root for trees staged into LDS, whose

@@ -1069,7 +1069,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
                 s->walk_starts.swap(starts);
             }
             // camera rays start at their tile's entry (rtmi_tuning::cam_entry; host: build_tile_entries, csrc/rtmi_host.cpp)
-            if (s->accel == RTMI_ACCEL_BVH && (tune.cam_entry == 2u || (tune.cam_entry == 0u && !s->big)) && walk_root != kNoWalkRef && !(walk_root & kLeafBit)) {
+            if (s->accel == RTMI_ACCEL_BVH && (tune.cam_entry == 2u || (tune.cam_entry == 0u && (!s->big || s->d_walk_starts != nullptr))) && walk_root != kNoWalkRef && !(walk_root & kLeafBit)) {
                 const auto t0 = std::chrono::steady_clock::now();
                 std::vector<uint32_t> entries;
                 build_tile_entries(*camera, objects, s->bvh, walk_root, entries);
@@ -1108,6 +1108,10 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     HIP_TRY_S(hipGetDeviceProperties(&prop, dev));
     if (tune.blocks_per_cu) per_cu = std::max(1, std::min(per_cu, (int)tune.blocks_per_cu));
     if (!s->big && s->accel == RTMI_ACCEL_BVH && s->d_tile_entry != nullptr) s->wait_thresh = 56u;
+    // (trees in HBM whose scattered rays start in their own leaf: those lanes are done after a few trips, and a round that leaves the
+    // loop earlier lets them shade while the camera and ground rays carry their walks over -- config 4 at 64 spp, way on, threshold
+    // 52 / 48 / 44 / 40: 75.0 / 72.2 / 71.3 / 71.1 ms, against 74.2 - 75.9 for walks from the root at any of them)
+    if (s->big && s->accel == RTMI_ACCEL_BVH && s->d_walk_starts != nullptr) s->wait_thresh = 44u;
     if (tune.wait_thresh) s->wait_thresh = std::min(64u, tune.wait_thresh);
 
     if (tune.chunk_samples) s->chunk = tune.chunk_samples < 0 ? 0u : (uint32_t)tune.chunk_samples; // 0: split off

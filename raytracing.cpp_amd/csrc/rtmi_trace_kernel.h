@@ -224,13 +224,21 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             // tests them like any node (host: build_walk_starts; exact for any start).  One 64-byte record per slot.
             if (origin_slot < P.n_slots) {
                 const uint4* R = P.walk_starts + 4u * origin_slot;
+#ifndef RTMI_WAY_ONE_BATCH
+#define RTMI_WAY_ONE_BATCH 1 // 1: the four 16-byte reads of a start record in flight together (0: the second pair only when some lane needs it)
+#endif
                 const uint4 r0 = R[0], r1 = R[1];
+#if RTMI_WAY_ONE_BATCH
+                const uint4 r2 = R[2], r3 = R[3];
+#endif
                 const uint32_t n = r0.y;
                 t.cur = r0.x;
                 auto push = [&](uint32_t k, uint32_t id) { if (k < n) *stack_at(t.sp + k * sp_stride) = (StackS)id; };
                 push(0u, r0.z); push(1u, r0.w); push(2u, r1.x); push(3u, r1.y); push(4u, r1.z); push(5u, r1.w);
                 if (ballot(n > 6u) != 0ull) {
+#if !RTMI_WAY_ONE_BATCH
                     const uint4 r2 = R[2], r3 = R[3];
+#endif
                     push(6u, r2.x); push(7u, r2.y); push(8u, r2.z); push(9u, r2.w);
                     push(10u, r3.x); push(11u, r3.y); push(12u, r3.z); push(13u, r3.w);
                 }

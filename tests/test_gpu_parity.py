@@ -1016,10 +1016,12 @@ def test_camera_entries_do_not_change_the_image(pkg, ob, rtow, gpu):
     W, H = cam.img_width, cam.img_height
     want, want8 = ob.render_rect_counter(ocam, *rtow, 61, 0, 0, W, H, nthreads=8)
     tests = {}
-    for tun in (dict(), dict(cam_entry=1), dict(force_hbm_scene=1, cam_entry=2), dict(force_hbm_scene=1), dict(chunk_samples=-1),
-                dict(tile_order=2, bands=3), dict(chain_mode=1, block_lanes=512)):
+    for tun in (dict(), dict(cam_entry=1), dict(force_hbm_scene=1), dict(force_hbm_scene=1, cam_entry=1), dict(force_hbm_scene=1, walk_start=1),
+                dict(force_hbm_scene=1, walk_start=1, cam_entry=2), dict(chunk_samples=-1), dict(tile_order=2, bands=3),
+                dict(chain_mode=1, block_lanes=512)):
         with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, collect_stats=True, tuning=tun or None) as s:
-            on = tun.get("cam_entry", 0) == 2 or (tun.get("cam_entry", 0) == 0 and not tun.get("force_hbm_scene"))  # (default: trees in LDS)
+            # (default: trees in LDS, and trees in HBM whose scattered rays start in their own leaf)
+            on = tun.get("cam_entry", 0) == 2 or (tun.get("cam_entry", 0) == 0 and not (tun.get("force_hbm_scene") and tun.get("walk_start")))
             li = s.launch_info()
             assert li["cam_entry"] == (1 if on else 0) and (li["entry_build_us"] > 0) == on, (tun, li)
             rgb, rgba = s.render_rows(0, H, 61)
@@ -1033,7 +1035,8 @@ def test_camera_entries_do_not_change_the_image(pkg, ob, rtow, gpu):
                 assert st["segments"] == c["segments"]
                 assert abs(st["node_tests"] - c["node_tests"]) <= 1e-3 * c["node_tests"], (tun, st, c)
                 assert abs(st["sphere_tests"] - c["sphere_tests"]) <= 1e-3 * c["sphere_tests"], (tun, st, c)
-                tests[on, "force_hbm_scene" in tun] = st["node_tests"]
+                if not tun.get("walk_start"):
+                    tests[on, "force_hbm_scene" in tun] = st["node_tests"]
             part, _ = s.render_rows(5, 77, 61)
             _assert_frames_equal(part, want[5:77])
             rect, _ = s.render_rect(13, 3, 150, 88, 61)
