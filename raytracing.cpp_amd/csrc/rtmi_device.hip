@@ -186,7 +186,9 @@ struct rtmi_scene {
 
     uint32_t lds_att = 0, lds_pool = 0;
     uint32_t lds_top_nodes = 0; // HBM-resident trees: records staged into LDS (48 bytes each, the start of the device array): breadth-first nodes ...
-    uint32_t lds_top_ways = 0;  // ... of which this many are the shallowest way records (rtmi_tuning::walk_start)
+    uint32_t lds_top_ways = 0;  // ... of which this many slots are the block of top way records, placed by path code (rtmi_tuning::walk_start)
+    uint32_t way_jtop = 0, way_top_base = 0; // levels of way records in that block (two tree levels each) and its first index
+    uint32_t n_dev_nodes = 0;   // records of the device's node array (tree nodes + the sparse block + the deeper way records)
     uint32_t n_cus = 0;
     uint32_t root_ref_dev = 0; // root reference in the form the kernel variant expects
     uint32_t pre_leaf_dev[4] = {}; // leaves peeled off the top of the tree, tested at segment set-up
@@ -257,6 +259,8 @@ void fill_scene_params(const rtmi_scene* s, RtmiLaunch& P) {
     P.n_pre_leaves = s->n_pre_leaves;
     P.tile_entry = s->d_tile_entry;
     P.walk_starts = s->d_walk_starts;
+    P.way_jtop = s->way_jtop;
+    P.way_top_base = s->way_top_base;
     std::memcpy(P.pad_classes, s->bvh.pad_classes, sizeof(P.pad_classes));
     P.n_pad_classes = s->bvh.n_pad_classes;
     P.pad_eps = s->bvh.pad_eps;
@@ -900,11 +904,26 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
     // top of the tree = a spine of (leaf | subtree) nodes: hand up to four such leaves to segment set-up and start every walk below them
     uint32_t walk_root = s->bvh.root_ref, pre[4] = {};
     if (s->accel == RTMI_ACCEL_BVH && !s->bvh.nodes.empty()) walk_root = peel_top_leaves(s->bvh, pre, s->n_pre_leaves);
-    // scattered rays of trees that stay in HBM start in their own leaf (rtmi_tuning::walk_start): way records behind the nodes
-    std::vector<uint32_t> starts, node_perm, way_depth; // node_perm: builder's node index -> position in the device array (empty: identity)
+    // HBM-resident trees: how many 48-byte records the stacks leave room for in the 80 KiB of a workgroup (two per CU): the 100k-sphere
+    // tree of config 4 has 18 levels = 61 KB of 32-bit stack entries for 768 lanes, which leaves 384 (rtmi_tuning::lds_top_nodes caps
+    // it: n > 0 = at most n - 1)
+    uint64_t k_budget = 0;
+    if (s->big && s->accel == RTMI_ACCEL_BVH && !s->bvh.nodes.empty()) {
+        const uint64_t fixed = (uint64_t)s->stack_depth * s->block * 4u + (uint64_t)(s->block / 64u) * 80u + 64u;
+        k_budget = fixed < 80u * 1024u ? (80u * 1024u - fixed) / 48u : 0u;
+        if (tune.lds_top_nodes) k_budget = std::min<uint64_t>(k_budget, tune.lds_top_nodes - 1u);
+    }
+    // Scattered rays of trees that stay in HBM start in their own leaf (rtmi_tuning::walk_start): way records behind the nodes.
+    // The way records of the TOP levels (two levels a record: 4, 16, 64, 256 possible records for the pairs down to depth 8) are
+    // placed by their path code in a block of the staged records -- `way_jtop` levels, as many as fit while five levels of nodes
+    // still do -- so that the device computes their indices and a start record only has to name the (at most four) deeper ones.
+    std::vector<uint32_t> starts, node_perm, way_depth, way_code; // node_perm: builder's node index -> position in the device array (empty: identity)
+    auto top_slots = [](uint32_t j) { return ((1u << (2u * (j + 1u))) - 4u) / 3u; }; // 4 + 16 + ... + 4^j
+    uint32_t way_jtop = 0;
+    while (way_jtop < 4u && top_slots(way_jtop + 1u) + std::min<uint64_t>(31u, s->n_tree_nodes) <= k_budget) ++way_jtop;
     if (s->accel == RTMI_ACCEL_BVH && s->big && tune.walk_start != 1u && walk_root != kNoWalkRef && !(walk_root & kLeafBit) &&
         !s->bvh.nodes.empty()) {
-        build_walk_starts(s->bvh, walk_root, starts, &way_depth);
+        build_walk_starts(s->bvh, walk_root, starts, &way_depth, &way_code, way_jtop + 4u);
         if (s->bvh.nodes.size() == s->n_tree_nodes) starts.clear(); // (no sphere has a way: a tree of two levels)
     }
     uint32_t off = 0;
@@ -919,41 +938,31 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
         off += n_materials * 16u;
         off = align16(off);
     } else if (s->accel == RTMI_ACCEL_BVH && !s->bvh.nodes.empty()) {
-        // the top of the tree in what the stacks leave of the 80 KiB (two workgroups per CU): the 100k-sphere tree of config 4
-        // has 18 levels = 61 KB of 32-bit stack entries for 768 lanes, which leaves 384 of its 32 902 nodes -- its first eight
-        // levels and half of the ninth (rtmi_tuning::lds_top_nodes caps it: n > 0 = at most n - 1 nodes)
-        const uint64_t fixed = (uint64_t)s->stack_depth * s->block * 4u + (uint64_t)(s->block / 64u) * 80u + 64u;
-        uint64_t k = fixed < 80u * 1024u ? (80u * 1024u - fixed) / 48u : 0u;
-        k = std::min<uint64_t>(k, s->bvh.nodes.size()); // (way records included)
-        if (tune.lds_top_nodes) k = std::min<uint64_t>(k, tune.lds_top_nodes - 1u);
-        s->lds_top_nodes = (uint32_t)k;
-        // The staged records are shared between the tree's first breadth-first nodes and the SHALLOWEST way records: scattered rays
-        // never read the top nodes any more, they read the way records of their path's top levels -- which many leaves share (4 + 16 +
-        // 64 + 256 records cover the levels down to 8) -- and with every way record in memory the scheme measured +2 % SLOWER than
-        // walks from the root on config 4, whose first 8 levels had been LDS reads.  The device array is a permutation of bvh.nodes:
-        // [top nodes | top ways | other nodes | other ways]; every reference handed to the device goes through node_perm; what the
-        // library exports (rtmi_scene_get_bvh, rtmi_scene_get_walk_starts) keeps the builder's numbering.
-        if (!starts.empty() && k != 0u) {
-            const uint32_t n_tree = s->n_tree_nodes, n_all = (uint32_t)s->bvh.nodes.size(), kk = (uint32_t)k;
-            std::vector<uint32_t> by_depth(n_all - n_tree);
-            for (uint32_t i = 0; i < by_depth.size(); ++i) by_depth[i] = i;
-            std::stable_sort(by_depth.begin(), by_depth.end(), [&](uint32_t a, uint32_t b) { return way_depth[a] < way_depth[b]; });
-            // whole levels of ways while at least 31 slots (five levels of nodes) stay for the tree's own top
-            uint32_t k2 = 0;
-            while (k2 < by_depth.size()) {
-                uint32_t e = k2;
-                while (e < by_depth.size() && way_depth[by_depth[e]] == way_depth[by_depth[k2]]) ++e;
-                if (e + std::min(31u, n_tree) > kk) break;
-                k2 = e;
-            }
-            const uint32_t k1 = std::min(n_tree, kk - k2);
-            node_perm.assign(n_all, 0u);
+        // The staged records: the tree's first breadth-first nodes -- the levels every walk from the root passes through -- and, with
+        // walk starts, the block of top way records (scattered rays never read the top nodes any more: with every way record in memory
+        // the scheme measured +2 % SLOWER than walks from the root on config 4, whose first 8 levels had been LDS reads).  The device
+        // array is a rearrangement of bvh.nodes: [top nodes | top ways by path code (sparse) | other nodes | deeper ways]; every
+        // reference handed to the device goes through node_perm; what the library exports keeps the builder's numbering.
+        uint64_t k = std::min<uint64_t>(k_budget, s->n_tree_nodes);
+        s->n_dev_nodes = s->n_tree_nodes;
+        if (!starts.empty()) {
+            const uint32_t n_tree = s->n_tree_nodes, n_ways = (uint32_t)s->bvh.nodes.size() - n_tree;
+            const uint32_t k2 = top_slots(way_jtop), k1 = (uint32_t)std::min<uint64_t>(n_tree, k_budget - k2);
+            node_perm.assign(n_tree + n_ways, 0u);
             for (uint32_t i = 0; i < n_tree; ++i) node_perm[i] = i < k1 ? i : i + k2;
-            for (uint32_t j = 0; j < by_depth.size(); ++j) node_perm[n_tree + by_depth[j]] = j < k2 ? k1 + j : n_tree + j;
-            s->lds_top_nodes = k1 + k2;
+            uint32_t deep = 0;
+            for (uint32_t w = 0; w < n_ways; ++w) {
+                const uint32_t level = way_depth[w] / 2u; // 1 = the pair of levels below the walk's root
+                if (level <= way_jtop) node_perm[n_tree + w] = k1 + (top_slots(level - 1u)) + way_code[w];
+                else node_perm[n_tree + w] = n_tree + k2 + deep++;
+            }
+            s->n_dev_nodes = n_tree + k2 + deep;
             s->lds_top_ways = k2;
-            k = s->lds_top_nodes;
+            s->way_jtop = way_jtop;
+            s->way_top_base = k1;
+            k = k1 + k2;
         }
+        s->lds_top_nodes = (uint32_t)k;
         off = align16((uint32_t)k * 48u);
     }
     s->lds_stack = off;
@@ -1040,7 +1049,7 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
                 std::memcpy(&h, &b, 2);
                 return (float)h;
             };
-            std::vector<uint32_t> rec(dn.size() * 12u, 0u);
+            std::vector<uint32_t> rec((size_t)std::max<uint32_t>(s->n_dev_nodes, (uint32_t)dn.size()) * 12u, 0u);
             for (size_t i = 0; i < dn.size(); ++i) {
                 uint32_t* r = &rec[(node_perm.empty() ? i : (size_t)node_perm[i]) * 12u];
                 for (int k = 0; k < 2; ++k)
@@ -1059,11 +1068,30 @@ static int scene_create_impl(const rtmi_camera* camera, const rtmi_object* objec
             }
             HIP_TRY_S(upload(&s->d_nodes, rec.data(), rec.size() * sizeof(uint32_t)));
             if (!starts.empty()) {
-                std::vector<uint32_t> dev_starts = starts;
-                for (size_t sl = 0; sl < dev_starts.size() / 16u; ++sl) {
-                    uint32_t* r = &dev_starts[sl * 16u];
-                    r[0] = dev_ref(r[0]);
-                    for (uint32_t q = 0; q < r[1] && q < 14u; ++q) r[2u + q] = dev_ref(r[2u + q]);
+                // the device's start records: 16 bytes a slot {start reference | n, path code of the top levels, the deeper way indices
+                // as 20-bit fields}: one load where the exported form has four, a table of 1.6 MB instead of 6.4 MB for 100k spheres
+                const size_t n_sl = starts.size() / 16u;
+                std::vector<uint32_t> dev_starts(n_sl * 4u, 0u);
+                for (size_t sl = 0; sl < n_sl; ++sl) {
+                    const uint32_t* r = &starts[sl * 16u];
+                    uint32_t* d = &dev_starts[sl * 4u];
+                    uint32_t n = std::min(r[1], s->way_jtop + 4u);
+                    const uint32_t n_top = std::min(n, s->way_jtop);
+                    uint64_t ids[4] = {0, 0, 0, 0};
+                    bool fits = true;
+                    for (uint32_t q = 0; n_top + q < n; ++q) {
+                        ids[q] = dev_ref(r[2u + n_top + q]);
+                        fits = fits && ids[q] < (1u << 20);
+                    }
+                    if (!fits || r[1] > s->way_jtop + 4u) { // (cannot be named in 20 bits / deeper than the builder was asked for: from the root)
+                        d[0] = dev_ref(walk_root);
+                        continue;
+                    }
+                    const uint32_t code_top = n_top ? (r[14] >> (2u * (n - n_top))) & 0xffu : 0u; // the path code at level n_top
+                    d[0] = dev_ref(r[0]);
+                    d[1] = n | (code_top << 4) | ((uint32_t)ids[0] << 12);
+                    d[2] = (uint32_t)ids[1] | ((uint32_t)(ids[2] & 0xfffu) << 20);
+                    d[3] = (uint32_t)(ids[2] >> 12) | ((uint32_t)ids[3] << 8);
                 }
                 HIP_TRY_S(upload(&s->d_walk_starts, dev_starts.data(), dev_starts.size() * sizeof(uint32_t)));
                 s->walk_starts.swap(starts);

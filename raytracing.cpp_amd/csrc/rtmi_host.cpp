@@ -761,10 +761,12 @@ uint32_t peel_top_leaves(const Bvh& bvh, uint32_t pre[4], uint32_t& n_pre) {
 // unchanged hand-written node step tests two levels a trip, pushes what it hits and pops the next record.  Round 5 built the same
 // idea with per-level sibling lists tested by a compiled loop at segment set-up and lost 14-31 %; the replay of the kernel's rounds
 // (tools/wave_replay.py grid) scored this form first: node trips per round 17.5 -> 13.2 on the grid.
-// Output: way records appended to `nodes` (indices >= the tree's node count), and per sphere SLOT one 64-byte start record
-// {start reference, n, way record indices top of the tree first (popped last), padding}; n = 0 and the walk's root where there is
-// no way (leaves one or two levels below the root, peeled leaves).
-void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& start_records, std::vector<uint32_t>* way_depth) {
+// Output: way records appended to `nodes` (indices >= the tree's node count), and per sphere SLOT one 16-word start record
+// {start reference, n <= max_ways, way record indices top of the tree first (popped last), ..., word 14: the start's path code}; n = 0
+// and the walk's root where there is no way (leaves one or two levels below the root, peeled leaves).  This is the form the library
+// exports (rtmi_scene_get_walk_starts); the device reads a 16-byte packing of it (csrc/rtmi_device.hip).
+void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& start_records, std::vector<uint32_t>* way_depth,
+                       std::vector<uint32_t>* way_code, uint32_t max_ways) {
     const uint32_t n_slots = (uint32_t)bvh.slot_object.size();
     start_records.assign((size_t)n_slots * 16u, 0u);
     for (uint32_t sl = 0; sl < n_slots; ++sl) start_records[(size_t)sl * 16u] = walk_root;
@@ -795,7 +797,15 @@ void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& star
             el[e] = El{c, n, el[n].depth + 1u, k};
         }
     }
-    constexpr uint32_t kMaxWays = 14; // ids of one 64-byte start record
+    const uint32_t kMaxWays = std::min(std::max(max_ways, 1u), 12u); // (12 ids + two words of path code fit one 64-byte start record)
+    // path code of an element: two bits per pair of levels -- (side at depth 2j - 1) << 1 | side at depth 2j -- the top pair in the
+    // most significant position: the device places the way records of the top levels BY this code (csrc/rtmi_device.hip)
+    auto path_code = [&](uint32_t e) {
+        uint32_t code = 0, shift = 0;
+        for (uint32_t x = e; el[x].depth >= 2u; x = el[el[x].parent].parent, shift += 2u)
+            code |= ((el[el[x].parent].side << 1) | el[x].side) << shift;
+        return code;
+    };
     std::vector<uint32_t> way_of(el.size(), 0xffffffffu);
     auto way = [&](uint32_t e) { // the way record of even-depth element e (depth >= 2): the sibling of its parent, its own sibling
         if (way_of[e] != 0xffffffffu) return way_of[e];
@@ -809,6 +819,7 @@ void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& star
         way_of[e] = (uint32_t)bvh.nodes.size();
         bvh.nodes.push_back(v);
         if (way_depth) way_depth->push_back(el[e].depth); // (the deeper of the two levels the record covers)
+        if (way_code) way_code->push_back(path_code(e));
         return way_of[e];
     };
     for (uint32_t sl = 0; sl < n_slots; ++sl) {
@@ -817,12 +828,13 @@ void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& star
         if (el[e].depth & 1u) e = el[e].parent;
         while (el[e].depth > 2u * kMaxWays) e = el[el[e].parent].parent;
         if (el[e].depth == 0u) continue;
-        uint32_t chain[kMaxWays], m = 0;
+        uint32_t chain[12], m = 0;
         for (uint32_t x = e; el[x].depth >= 2u; x = el[el[x].parent].parent) chain[m++] = way(x);
         uint32_t* r = &start_records[(size_t)sl * 16u];
         r[0] = el[e].ref;
         r[1] = m;
         for (uint32_t i = 0; i < m; ++i) r[2u + i] = chain[m - 1u - i]; // top of the tree first: the deepest record is popped first
+        r[14] = path_code(e); // (2 m bits)
     }
 }
 
@@ -1089,7 +1101,7 @@ extern "C" int rtmi_walk_starts_build(const rtmi_object* objects, uint32_t n_obj
         uint32_t pre[4], n_pre = 0;
         const uint32_t walk_root = peel_top_leaves(bvh, pre, n_pre);
         std::vector<uint32_t> starts;
-        build_walk_starts(bvh, walk_root, starts, nullptr);
+        build_walk_starts(bvh, walk_root, starts, nullptr, nullptr, 12u);
         if (n_nodes_out) *n_nodes_out = static_cast<uint32_t>(bvh.nodes.size());
         if (n_tree_nodes_out) *n_tree_nodes_out = n_tree;
         if (nodes_out && !bvh.nodes.empty()) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtmi_bvh_node));

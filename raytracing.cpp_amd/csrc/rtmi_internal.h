@@ -55,7 +55,8 @@ inline uint32_t default_bvh_passes(uint32_t n_objects) { return n_objects > 0x20
 void build_bvh(const rtmi_object* objects, uint32_t n, uint32_t leaf_size, uint32_t optimise_passes, Bvh& out);
 bool pad_refine_pays(const float (*classes)[8], uint32_t n_classes, float pad_eps);
 uint32_t peel_top_leaves(const Bvh& bvh, uint32_t pre[4], uint32_t& n_pre);
-void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& start_records, std::vector<uint32_t>* way_depth);
+void build_walk_starts(Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& start_records, std::vector<uint32_t>* way_depth,
+                       std::vector<uint32_t>* way_code, uint32_t max_ways);
 void build_tile_entries(const rtmi_camera& cam, const rtmi_object* objects, const Bvh& bvh, uint32_t walk_root, std::vector<uint32_t>& entries);
 
 } // namespace rtmi

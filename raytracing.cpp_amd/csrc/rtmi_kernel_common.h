@@ -42,9 +42,12 @@ struct RtmiLaunch {
     // camera rays: where the walks of the samples of each 8x8 tile of the WHOLE image start (tile = (gy / 8) * gtiles_x + px / 8): a
     // node or leaf reference in the kernel variant's format, kStackEnd = the tile's beam meets no sphere of the tree; NULL: the root
     const uint32_t* tile_entry;
-    // scattered rays (HBM-resident trees): per sphere slot one 64-byte start record {reference the walk of a ray off that sphere starts
-    // at, n, indices of the n way records pre-loaded on its stack (top of the tree first)} (host: build_walk_starts); NULL: the root
+    // scattered rays (HBM-resident trees): per sphere slot one 16-byte start record {x: reference the walk of a ray off that sphere
+    // starts at; y: n | path code of the top levels << 4 | deeper way index 0 << 12; z, w: deeper way indices 1-3, 20 bits each}: the
+    // n way records pre-loaded on the stack are, for the first min(n, way_jtop) levels, at way_top_base + (4^j - 4) / 3 + (code >>
+    // 2 (n_top - j)) -- placed by path code in the staged block -- and the named ones below (host: build_walk_starts); NULL: the root
     const uint4* walk_starts;
+    uint32_t way_jtop, way_top_base;
     float pad_classes[kMaxPadClasses][8];
     uint32_t n_pad_classes;
     float pad_eps, pad_floor;

@@ -116,6 +116,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
     Trav t{};
     t.cur = kStackEnd; // "not walking" (see the traversal loop)
     uint32_t st_segments = 0, st_sphere = 0, st_node = 0, st_samples = 0, st_item0 = 0;
+    uint32_t ws1 = 0, ws2 = 0, ws3 = 0; // HBM-resident trees with walk starts: the start record of the segment about to begin (see begin_segment)
     PF_DECL
     PB_DECL
 
@@ -215,33 +216,27 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
         t.d = d;
         t.a = vdot(d, d);
         t.tbest = __builtin_inff();
-        const uint32_t origin_slot = t.best; // the sphere a scattered ray starts on (the hit it was scattered at); ~0u for a camera ray
         t.best = ~0u;
         t.sp = lds0 + P.lds_stack + threadIdx.x * (uint32_t)sizeof(StackT) + sp_stride; // entry 1 (entry 0: the sentinel)
         if (ACCEL == RTMI_ACCEL_BVH && BIG && P.walk_starts != nullptr) {
-            // A ray scattered off a sphere of the tree starts its walk in that sphere's own leaf, the siblings hanging off the path
-            // above it pre-loaded on the stack as WAY records -- two levels a record, in the node format, so that the node loop
-            // tests them like any node (host: build_walk_starts; exact for any start).  One 64-byte record per slot.
-            if (origin_slot < P.n_slots) {
-                const uint4* R = P.walk_starts + 4u * origin_slot;
-#ifndef RTMI_WAY_ONE_BATCH
-#define RTMI_WAY_ONE_BATCH 1 // 1: the four 16-byte reads of a start record in flight together (0: the second pair only when some lane needs it)
-#endif
-                const uint4 r0 = R[0], r1 = R[1];
-#if RTMI_WAY_ONE_BATCH
-                const uint4 r2 = R[2], r3 = R[3];
-#endif
-                const uint32_t n = r0.y;
-                t.cur = r0.x;
-                auto push = [&](uint32_t k, uint32_t id) { if (k < n) *stack_at(t.sp + k * sp_stride) = (StackS)id; };
-                push(0u, r0.z); push(1u, r0.w); push(2u, r1.x); push(3u, r1.y); push(4u, r1.z); push(5u, r1.w);
-                if (ballot(n > 6u) != 0ull) {
-#if !RTMI_WAY_ONE_BATCH
-                    const uint4 r2 = R[2], r3 = R[3];
-#endif
-                    push(6u, r2.x); push(7u, r2.y); push(8u, r2.z); push(9u, r2.w);
-                    push(10u, r3.x); push(11u, r3.y); push(12u, r3.z); push(13u, r3.w);
-                }
+            // A ray scattered off a sphere of the tree starts its walk in that sphere's own leaf (t.cur: set with the record, below), the
+            // siblings hanging off the path above it pre-loaded on the stack as WAY records -- two levels a record, in the node format,
+            // so that the node loop tests them like any node (host: build_walk_starts; exact for any start).  The 16-byte
+            // start record was read when the ray was scattered (ws1-3, a round ago: its latency is behind the rest of that round): n,
+            // the path code that places the top levels' records in the staged block, the deeper records by index.
+            const uint32_t n = ws1 & 15u, code = (ws1 >> 4) & 255u, n_top = min(n, P.way_jtop);
+            auto push = [&](uint32_t k, uint32_t id) { if (k < n) *stack_at(t.sp + k * sp_stride) = (StackS)id; };
+            if (ballot(n != 0u) != 0ull) {
+                // level j = 1 .. n_top at way_top_base + (4^j - 4) / 3 + the first 2 j bits of the code
+                const uint32_t sh = 2u * n_top;
+                if (n_top >= 1u) push(0u, P.way_top_base + 0u + (code >> ((sh - 2u) & 31u)));
+                if (n_top >= 2u) push(1u, P.way_top_base + 4u + (code >> ((sh - 4u) & 31u)));
+                if (n_top >= 3u) push(2u, P.way_top_base + 20u + (code >> ((sh - 6u) & 31u)));
+                if (n_top >= 4u) push(3u, P.way_top_base + 84u + (code >> ((sh - 8u) & 31u)));
+                push(n_top + 0u, ws1 >> 12);
+                push(n_top + 1u, ws2 & 0xfffffu);
+                push(n_top + 2u, (ws2 >> 20) | ((ws3 & 0xffu) << 12));
+                push(n_top + 3u, (ws3 >> 8) & 0xfffffu);
                 t.sp += n * sp_stride;
             }
         }
@@ -448,7 +443,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
             } else {
                 t.o = origin;
                 t.d = vsub(pixel_sample, origin);
-                if (ACCEL == RTMI_ACCEL_BVH && BIG) t.best = ~0u; // (begin_segment reads where a scattered ray starts from t.best)
+                if (ACCEL == RTMI_ACCEL_BVH && BIG) ws1 = 0u; // (a camera ray: no way records; t.cur is its tile's entry or the root)
                 phase = PH_BEGIN;
             }
         }
@@ -714,6 +709,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                         t.o = p;
                         t.d = sd;
                         if (ACCEL == RTMI_ACCEL_BVH) t.cur = P.root_ref;
+                        if (ACCEL == RTMI_ACCEL_BVH && BIG && P.walk_starts != nullptr) {
+                            // (the start record of the ray just scattered off sphere t.best, read NOW: it is used by the next round's
+                            // segment set-up -- a dependent 64-byte read there measured 1.4 % of the config-4 frame)
+                            const uint4 ws = P.walk_starts[t.best];
+                            t.cur = ws.x;
+                            ws1 = ws.y; ws2 = ws.z; ws3 = ws.w;
+                        }
                         phase = PH_BEGIN; // set up before the next traversal, together with the new primary rays
                     }
                 }

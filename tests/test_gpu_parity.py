@@ -170,11 +170,12 @@ def test_launch_info_reports_what_the_tuning_resolved_to(pkg, rtow, gpu):
         old[0] = 36
         assert pkg.lib().rtmi_scene_get_launch_info(s._h, C.cast(old, C.POINTER(pkg.LaunchInfo))) == pkg.RTMI_ERR_BAD_ARG
     # HBM-resident trees: the top of the tree is staged into LDS (as many breadth-first nodes as fit next to the stacks; here the
-    # whole 288-node tree), rtmi_tuning::lds_top_nodes caps it (n > 0: at most n - 1 nodes)
+    # whole 288-node tree, and with walk starts the 4 + 16 + 64 + 256 slots of the top way records, placed by path code),
+    # rtmi_tuning::lds_top_nodes caps it (n > 0: at most n - 1 records)
     for cap, want_top in ((0, None), (1, 0), (41, 40)):
         with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BVH, tuning=dict(force_hbm_scene=1, lds_top_nodes=cap)) as s:
             li3 = s.launch_info()
-            assert li3["scene_in_lds"] == 0 and li3["lds_top_nodes"] == (len(s.bvh()["nodes"]) if want_top is None else want_top)  # (way records included)
+            assert li3["scene_in_lds"] == 0 and li3["lds_top_nodes"] == (s.bvh()["n_tree_nodes"] + 340 if want_top is None else want_top)  # (the whole tree + the block of top way records)
             assert li3["pad_mode"] == 1
     with pkg.Scene(cam, *rtow, accel=pkg.ACCEL_BRUTE) as s:
         assert s.launch_info()["pad_mode"] == 0 and s.launch_info()["lds_top_nodes"] == 0

@@ -271,7 +271,7 @@ def test_walk_starts_keep_the_walk_exact(pkg, ob, rtow):
         bvh = pkg.bvh_build(objs, leaf)
         nodes, n_tree, rec = pkg.walk_starts_build(objs, leaf)
         assert n_tree == len(bvh["nodes"]) and nodes[:n_tree].tobytes() == bvh["nodes"].tobytes()
-        assert rec.shape == (len(objs), 16) and (rec[:, 1] <= 14).all()
+        assert rec.shape == (len(objs), 16) and (rec[:, 1] <= 12).all()
         ways = rec[:, 2:][np.arange(14)[None, :] < rec[:, 1:2]]
         assert ((ways >= n_tree) & (ways < len(nodes))).all()  # way records sit behind the tree's own nodes
         base = dict(bvh, nodes=bvh["nodes"].view(ob.BVH_NODE_DTYPE))
