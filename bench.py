@@ -588,6 +588,19 @@ def main(argv=None):
                 for k in ctr:
                     ctr[k] += c[k]
         fps = flops_per_sample(ctr)
+        # the same count for walks that all start at the root (rounds 1-5's algorithm): camera entries and walk starts make the
+        # ALGORITHM cheaper, so `roofline.frac` -- priced on the work of the walk as it runs, as SURVEY 8(d) asks -- can fall while the
+        # kernel gets faster; frac_at_root_walk_work keeps the yardstick of the earlier rounds' lines beside it
+        fps_root = fps
+        if bvh is not None and (bvh.get("entries") is not None or bvh.get("walk_starts") is not None):
+            plain = dict(bvh, entries=None, walk_starts=None)
+            ctr0 = {k: 0 for k in ctr}
+            for y in range(ctr_stride // 2, H, ctr_stride):
+                for x in range(ctr_stride // 2, W, ctr_stride * 4):
+                    _, _, c = ob.render_rect_counter(ccam, objs, mats, RENDER_SEED, x, y, x + 1, y + 1, counters=True, bvh=plain)
+                    for k in ctr0:
+                        ctr0[k] += c[k]
+            fps_root = flops_per_sample(ctr0)
         # (what was launched, not what the scene is eligible for: a launch whose chain slots could not be allocated falls back
         # to run-length encoded chains and says so in packed_chain_fallbacks)
         li = scene.launch_info() if scene is not None else {}
@@ -632,6 +645,11 @@ def main(argv=None):
             "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note,
             "kernel": "rtmi_trace_kernel<%s>" % args.accel, "kernel_ms": round(kernel_s * 1e3, 3),
             "flops_per_sample": round(fps, 1),
+            "flops_per_sample_root_walk": round(fps_root, 1),
+            "frac_at_root_walk_work": round(samples_per_launch * fps_root / kernel_s / 1e12 / VALU_PEAK_TFLOPS, 5),
+            "frac_note": "frac = the work of the walk AS IT RUNS (camera rays from their tile's entry, scattered rays of HBM-resident trees "
+                         "from their own leaf: fewer box tests per sample than a walk from the root); frac_at_root_walk_work = the same "
+                         "time against the work of rounds 1-5's walk from the root, the yardstick of the earlier rounds' lines",
             "counters_per_sample": {k: round(ctr[k] / ctr["samples"], 3) for k in ctr if k not in ("samples", "hit_lambertian", "hit_metallic")},
             "counters_source": f"oracle instrumented walk, {ctr['samples']} samples on a uniform pixel subset",
             # scene staged once per workgroup-resident CU + 16-byte sample records written once (the ordered resolve
