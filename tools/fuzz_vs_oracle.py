@@ -2,7 +2,8 @@
 three materials, bounce limits 1-120, defocus on and off; every fourth world wide -- up to 600 spheres over hundreds of radii, where
 the reach-bounded box pad of round 4 is the library's choice) through the walk and the scan, each with the scene in LDS, forced into
 HBM (top of the tree staged / not staged / 9 nodes staged), run-length encoded chains, whole-pixel work items, either pad rule forced,
-the plain and the post-optimised tree, cost-ordered tiles in three overlapped bands; every float must match (NaN = NaN).
+the plain and the post-optimised tree, cost-ordered tiles in three sequential bands, and (round 6) camera entries and walk starts on / off /
+forced in both memory layouts; every float must match (NaN = NaN).
 usage: fuzz_vs_oracle.py [seed] [cases]   (logs of the round-4 runs: profiles/r04_fuzz_vs_oracle.txt)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -22,7 +23,11 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
         tunings = (None, dict(force_hbm_scene=1), dict(chain_mode=1), dict(chunk_samples=-1), dict(tile_order=2, bands=3, chunk_samples=2))
         if accel == pkg.ACCEL_BVH:
             tunings += (dict(pad_mode=2), dict(pad_mode=1, bvh_passes=1), dict(pad_mode=2, force_hbm_scene=1, lds_top_nodes=1),
-                        dict(pad_mode=1, force_hbm_scene=1, lds_top_nodes=10, bvh_passes=9))
+                        dict(pad_mode=1, force_hbm_scene=1, lds_top_nodes=10, bvh_passes=9),
+                        # round 6: camera entries (default on in LDS) off, walk starts (default on in HBM) off / without entries / with a
+                        # staged block of one and of three levels of way records
+                        dict(cam_entry=1), dict(force_hbm_scene=1, walk_start=1), dict(force_hbm_scene=1, cam_entry=1),
+                        dict(force_hbm_scene=1, lds_top_nodes=40, wait_thresh=60), dict(force_hbm_scene=1, lds_top_nodes=120, pad_mode=2))
         for tun in tunings:
             with pkg.Scene(cam, objs, mats, accel=accel, tuning=tun) as s:
                 rgb, rgba = s.render_rows(0, cam.img_height, case)
