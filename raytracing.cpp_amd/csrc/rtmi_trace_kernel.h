@@ -19,6 +19,10 @@ constexpr uint32_t kBlackSample = 0xfffffffeu; // Trav::best of a sample that is
 #define RTMI_WALK_PRIO 1 // s_setprio of a wave inside the traversal loop (0 elsewhere)
 #endif
 
+#ifndef RTMI_BLOCK_LIST
+#define RTMI_BLOCK_LIST 1 // 0: no launches over a LIST of row blocks (rtmi_render_block_list_device): the A/B of what the look-up costs the others
+#endif
+
 #ifndef RTMI_ASM_WALK
 #define RTMI_ASM_WALK 1 // 0: the compiler's node step everywhere (the A/B and the fallback for a changed register budget)
 #endif
@@ -342,7 +346,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                     // (a launch over a LIST of row blocks -- the cost-balanced shards of a multi-GPU frame: blocks of a multiple of 8
                     // rows that start on multiples of 8 -- looks the tile's image row up once per refill: bits 16.. = that row / 8)
                     uint32_t gy8 = 0u;
-                    if (P.block_first_row != nullptr && next < P.n_work) {
+                    if (RTMI_BLOCK_LIST && P.block_first_row != nullptr && next < P.n_work) {
                         const uint32_t ply0 = trow_l * 8u, blk0 = fdiv(ply0, P.div_block_rows);
                         gy8 = (P.block_first_row[blk0] + (ply0 - blk0 * P.block_rows)) >> 3;
                     }
@@ -368,7 +372,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BIG ? RTMI_WPE_BIG : RTMI_WPE
                 const uint32_t px = P.x_first + (txy & 0xffffu) * 8u + (j & 7u), ply = (txy >> 16) * 8u + (j >> 3);
                 if (px < P.x_end && ply < P.n_local_rows) {
                     uint32_t gy; // local row -> row of the whole image
-                    if (P.block_first_row != nullptr) {
+                    if (RTMI_BLOCK_LIST && P.block_first_row != nullptr) {
                         gy = ((s_first >> 16) << 3) + (j >> 3);
                     } else {
                         const uint32_t blk = fdiv(ply, P.div_block_rows);
