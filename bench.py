@@ -366,7 +366,7 @@ def main(argv=None):
         # N = 8 -- segment counts balance to 0.1 % and the shards stay 4 % apart -- so the default stays the plan of rounds 1-5.)
         costs = scene.tile_costs() if (world > 1 and args.shard_plan == "cost") else None
         bc = pkg.block_costs(costs, H, BLOCK_ROWS) if costs is not None else np.zeros((H + BLOCK_ROWS - 1) // BLOCK_ROWS, np.uint64)
-        if use_dist:
+        if use_dist and args.shard_plan == "cost":  # (the default plan needs no exchange)
             t_bc = torch.from_numpy(bc.astype(np.int64)).to(dev if dist.get_backend() == "nccl" else "cpu")
             dist.broadcast(t_bc, src=0)
             bc = t_bc.cpu().numpy().astype(np.uint64)
